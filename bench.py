@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Headline benchmark: audio-seconds reconstructed per second, Griffin-Lim 60
+iterations, n_fft 2048 / hop 256, 80-band synthetic mels (BASELINE.json).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one batch that is already resident in
+HBM: mel (B,80,T) -> linear magnitude on MFMA (gl_mel_to_mag), 60 fused
+Griffin-Lim iterations from a resident start signal (gl_run), peak normalisation
+(gl_peak_normalise).  Workload at N=1 is BASELINE config 2: B=64 utterances of
+T=861 frames (10.089 s each).  With N>1 every rank processes its own 64
+utterances (per-utterance sharding, no collective on the data path): weak scaling.
+
+Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (the fused
+Griffin-Lim iteration): algorithmic HBM bytes per launch / its average duration
+measured with HIP events on the launch stream inside the timed region.
+`cpu_baseline` times the float64 loop-form oracle (the reference's algorithm) on
+one core for one utterance.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+SR = 22050
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def synth_mels(B, T, seed):
+    """exp(U), U ~ N(-2, 1.5^2) lightly smoothed over (time, band)."""
+    rng = np.random.default_rng(seed)
+    u = rng.normal(-2.0, 1.5, size=(B, 80, T)).astype(np.float32)
+    u = (u + np.roll(u, 1, axis=2) + np.roll(u, -1, axis=2)) / 3.0
+    u = (u + np.roll(u, 1, axis=1) + np.roll(u, -1, axis=1)) / 3.0
+    return np.exp(u).astype(np.float32)
+
+
+def cpu_baseline(N, H, T, iters, budget_s):
+    """Reference algorithm (float64 numpy loop form incl. the dead RMSE) on ONE core,
+    one utterance of the benchmark geometry, as many iterations as fit the budget."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import gl_oracle as orc     # checker / baseline only -- never on the product path
+    rng = np.random.default_rng(7)
+    mag = np.abs(rng.standard_normal((T, N // 2 + 1))).astype(np.float32)
+    x0 = rng.standard_normal(T * H + N)
+    t0 = time.perf_counter()
+    orc.griffin_lim_loop(mag, N, H, 2, x0=x0)
+    per_iter = (time.perf_counter() - t0) / 2
+    n = int(max(2, min(iters, budget_s / max(per_iter, 1e-6))))
+    t0 = time.perf_counter()
+    orc.griffin_lim_loop(mag, N, H, n, x0=x0)
+    dt = time.perf_counter() - t0
+    t_full = dt / n * iters                      # scaled to the metric's 60 iterations
+    audio_s = (T * H + N) / SR
+    return {"value": audio_s / t_full, "unit": "audio-s/s", "cores": 1, "kind": "port",
+            "sample": f"1 utterance (T={T}, n_fft {N}, hop {H}), {n} of {iters} iterations timed "
+                      f"({dt:.1f} s) and scaled to {iters}; float64 numpy loop form of "
+                      "audio_utilities.py:154-188 incl. the dead RMSE",
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
+    ap.add_argument("--frames", type=int, default=861)
+    ap.add_argument("--n-fft", type=int, default=2048)
+    ap.add_argument("--hop", type=int, default=256)
+    ap.add_argument("--iters", type=int, default=60)
+    ap.add_argument("--path", type=int, default=0, help="0 fused (default), 1 generic kernels")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg; 0 disables")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    n_gpus = world if world > 1 else 1
+    if args.gpus != n_gpus and rank == 0:
+        print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using {n_gpus}", file=sys.stderr)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    from tacotron2_amd import filters
+    from tacotron2_amd.plan import Plan
+
+    N, H, T, B, K = args.n_fft, args.hop, args.frames, args.batch, args.iters
+    F = N // 2 + 1
+    L = T * H + N
+    plan = Plan(N, H, T, B, dev)
+    plan.set_path(args.path)
+    fb = torch.from_numpy(filters.mel(SR, N, 80, 125, 7600)).to(dev)
+    mel = torch.from_numpy(synth_mels(B, T, 1234 + rank)).to(dev)         # this rank's shard
+    x0 = plan.randn((B, L), seed=42 + rank)                                # resident start signal
+    mag = torch.empty((B, T, F), dtype=torch.float32, device=dev)
+    x = torch.empty((B, L), dtype=torch.float32, device=dev)
+
+    gl_ms = []
+
+    def step(timed):
+        plan.mel_to_mag(fb, mel, out=mag)
+        if timed:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()                      # torch's current stream == the stream gl_run launches on
+        plan.run(mag, x0, K, out=x)
+        if timed:
+            e1.record()
+            gl_ms.append((e0, e1))
+        plan.peak_normalise(x, mode=0)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    finite = bool(torch.isfinite(x).all().item())
+    if rank == 0:
+        audio_s_total = n_gpus * B * L / SR * args.steps
+        value = audio_s_total / dt
+        # dominant kernel: one fused GL iteration over the rank's B utterances
+        iter_ms = sum(a.elapsed_time(b) for a, b in gl_ms) / (len(gl_ms) * K)
+        algo_bytes = B * (T * F * 4 + 2 * L * 4)          # read mag + read x + write x
+        achieved = algo_bytes / (iter_ms * 1e-3) / 1e9
+        out = {
+            "metric": "audio-seconds reconstructed/sec (GL 60 iters, n_fft 2048)",
+            "value": value, "unit": "audio-s/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE config 2: batch of 64 synthetic 10 s 80-band mels per GPU, "
+                                   "mel->linear + Griffin-Lim 60 iters + peak normalise",
+                       "n_fft": N, "hop": H, "frames": T, "iters": K, "batch_per_gpu": B,
+                       "global_batch": B * n_gpus, "audio_s_per_utt": L / SR,
+                       "parallelism": f"utterance-sharded x{n_gpus}, no data-path collective",
+                       "kernel_path": "fused" if args.path == 0 else "generic"},
+            "x_realtime_per_gpu": value / n_gpus,
+            "roofline": {"bound": "hbm", "kernel": "fused Griffin-Lim iteration (gl_run, one launch per iteration)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": iter_ms},
+            "outputs_finite": finite,
+        }
+        if args.cpu_seconds > 0 and n_gpus == 1:
+            out["cpu_baseline"] = cpu_baseline(N, H, T, K, args.cpu_seconds)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,119 @@
+/*
+ * gl_hip.h  --  C-ABI of libgl_hip.so: MI355X (gfx950) Griffin-Lim vocoder kernels.
+ *
+ * Drop-in boundary for the reference's griffin_lim.py / audio_utilities.py path
+ * (AidenMoosa/Tacotron2).  The reference is pure Python/numpy, so the "FFI" a
+ * maintainer binds is ctypes; every entry point below names
+ * the reference function (file:line) whose numpy calls it replaces.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and integer sizes only; no torch / HIP types.
+ *   - All data pointers are DEVICE pointers to fp32 unless a comment says host.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls
+ *     enqueue work and return; they never synchronise the device.
+ *   - Every function returns 0 on success or a negative gl_status; the text of the
+ *     last failure on the calling thread is returned by gl_last_error().
+ *   - Geometry: N = n_fft (power of two, 64..4096), H = hop (>=1), T = frames,
+ *     F = N/2+1 bins, L = T*H + N samples   (audio_utilities.py:109-110,173-174).
+ *   - A plan is bound to one device and one (N, H); it owns the window, twiddle
+ *     tables and scratch.  One plan must not be used from two threads at once.
+ */
+#ifndef GL_HIP_H_
+#define GL_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gl_plan gl_plan;
+
+enum gl_status {
+    GL_OK = 0,
+    GL_ERR_INVALID = -1,   /* bad argument (geometry, null pointer, size beyond plan) */
+    GL_ERR_HIP = -2,       /* a HIP runtime call failed; see gl_last_error()          */
+    GL_ERR_NOMEM = -3,     /* device allocation failed                                */
+    GL_ERR_UNSUPPORTED = -4
+};
+
+/* Library/ABI version (major*100 + minor). */
+int gl_version(void);
+
+/* Text of the last error raised on this thread ("" if none). */
+const char* gl_last_error(void);
+
+/* L = T*H + N                                     audio_utilities.py:110,174 */
+long long gl_signal_length(int n_fft, int hop, int frames);
+
+/* len(range(0, len - N, H)): frames the reference STFT produces for a signal of
+ * `len` samples (0 when len <= N)                  audio_utilities.py:91-92   */
+int gl_num_frames(int n_fft, int hop, long long len);
+
+/* Create / destroy a plan.  max_frames / max_batch bound T and B of later calls
+ * (scratch is sized from them).  Window = symmetric Hann, np.hanning(N)
+ * (audio_utilities.py:88,108), computed in double on the host, stored fp32.   */
+int gl_plan_create(int n_fft, int hop, int max_frames, int max_batch, int device, gl_plan** out);
+int gl_plan_destroy(gl_plan* plan);
+
+/* Bytes of device memory the plan currently holds (tables + scratch). */
+long long gl_plan_device_bytes(const gl_plan* plan);
+
+/* a-4  stft_for_reconstruction(x, fft_size, hopsamp)      audio_utilities.py:77-92
+ *   x : [B][x_stride] fp32, each row needs >= (T-1)*H + N valid samples
+ *   S : [B][T][F][2] fp32 (re, im interleaved == complex64), rows = time slices */
+int gl_stft(gl_plan* plan, const float* x, long long x_stride, float* S, int B, int T, void* stream);
+
+/* a-5  istft_for_reconstruction(X, fft_size, hopsamp)    audio_utilities.py:95-114
+ *   S : [B][T][F][2] fp32 complex;  y : [B][L] fp32, L = T*H+N.
+ *   Overlap-add of window*irfft(frame) in frame order, NO window-sum
+ *   normalisation; imag(DC) and imag(Nyquist) are ignored as numpy's irfft does;
+ *   the last H samples of every row are written as 0.                          */
+int gl_istft(gl_plan* plan, const float* S, float* y, int B, int T, void* stream);
+
+/* a-2 (first line)  np.dot(filterbank.T, mel).T              griffin_lim.py:18-19
+ *   filterbank : [n_mels][F] fp32 (the array librosa.filters.mel returns,
+ *                griffin_lim.py:13-14; any basis of that shape may be passed)
+ *   mel        : [B][n_mels][T] fp32;    mag : [B][T][F] fp32
+ *   fp32-input MFMA (v_mfma_f32_32x32x2_f32), exact fp32 fma chain over n_mels.   */
+int gl_mel_to_mag(gl_plan* plan, const float* filterbank, const float* mel, float* mag,
+                  int n_mels, int B, int T, void* stream);
+
+/* a-3 + a-6  reconstruct_signal_griffin_lim(mag, fft_size, hopsamp, iterations)
+ *                                                     audio_utilities.py:154-188
+ *   mag   : [B][T][F] fp32   (rows = time slices)
+ *   x0    : [B][L] fp32 start signal (the reference draws np.random.randn(L),
+ *           audio_utilities.py:176; the host wrapper draws it the same way or the
+ *           caller fills it with gl_randn)
+ *   x_out : [B][L] fp32; may alias x0.
+ *   Runs `iters` times  x <- ISTFT( mag * S/|S| ),  S = STFT(x), with |S|==0 ->
+ *   phase 1+0j (np.angle(0)==0, audio_utilities.py:181-183), entirely on
+ *   `stream` with no host synchronisation.  The dead RMSE (line 186) is not
+ *   computed.  iters == 0 copies x0 to x_out.                                  */
+int gl_run(gl_plan* plan, const float* mag, const float* x0, float* x_out,
+           int iters, int B, int T, void* stream);
+
+/* Select the code path gl_run / gl_stft / gl_istft use: 0 = auto (fused
+ * wave-per-frame kernels where the geometry has one, else generic),
+ * 1 = force the generic (any power-of-two N) kernels.  For tests/benchmarks.   */
+int gl_plan_set_path(gl_plan* plan, int path);
+
+/* Device standard-normal fill (Philox4x32-10 + Box-Muller), for throughput runs
+ * where bit-parity with numpy's MT19937 stream (audio_utilities.py:176) is not
+ * needed.  out : [n] fp32.  Deterministic in (seed, index).                     */
+int gl_randn(float* out, long long n, uint64_t seed, void* stream);
+
+/* a-2 (normalise step)  max_sample = max|x|; if max_sample > 1: x /= max_sample
+ *                                                        griffin_lim.py:27-29
+ *   x : [B][row_stride] fp32, first `len` samples of each row are used, in place
+ *   peaks : [B] fp32 out (max|x| per row before scaling); may be NULL
+ *   mode : 0 = reference behaviour (scale only when peak > 1)
+ *          1 = always scale to peak 1 (what save_audio_to_file then does anyway,
+ *              audio_utilities.py:202-204); rows with peak 0 are left untouched  */
+int gl_peak_normalise(gl_plan* plan, float* x, long long row_stride, long long len,
+                      float* peaks, int mode, int B, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GL_HIP_H_ */

@@ -1,0 +1,219 @@
+"""CPU oracle for the Griffin-Lim vocoder hot path  --  TEST INFRASTRUCTURE ONLY.
+
+This file is a plain-numpy restatement of the reference algorithm
+(AidenMoosa/Tacotron2: ``audio_utilities.py`` / ``griffin_lim.py``).  It is the
+*checker* for the HIP product path; nothing under ``tacotron2_amd/`` or
+``dropin/`` imports it.  Only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import this module.
+
+Parity status
+-------------
+* ``stft_loop / istft_loop / griffin_lim_loop`` (a-3, a-4, a-5, a-6) are PINNED:
+  ``oracle/make_golden.py`` imports the real reference
+  (``/root/reference/audio_utilities.py``) in the build container, checks this
+  restatement against it to <= 1e-12 and writes the golden vectors under
+  ``tests/golden/``.
+* ``pcm16_from_float`` (a-7) is pinned by hand-built known answers: the
+  reference's ``save_audio_to_file`` dies at ``array.tostring()`` on
+  Python >= 3.9 (audio_utilities.py:214) so it cannot be run end to end.
+* ``mel_filterbank_slaney`` (a-1) is PARITY UNPINNED: librosa is not installed,
+  not vendored and not version-pinned by the reference; this follows librosa's
+  documented algorithm (htk=False, norm='slaney').
+
+Every function cites the reference file:line it follows.
+"""
+import numpy as np
+
+
+# --------------------------------------------------------------------------
+# a-4  stft_for_reconstruction            audio_utilities.py:77-92
+# --------------------------------------------------------------------------
+def stft_loop(x, fft_size, hopsamp):
+    """Loop form, float64.  One rfft per frame, symmetric Hann (np.hanning,
+    audio_utilities.py:88), no padding / centring; frame i covers
+    x[i : i+fft_size] for i in range(0, len(x)-fft_size, hopsamp)
+    (audio_utilities.py:91-92)."""
+    fft_size = int(fft_size)
+    hopsamp = int(hopsamp)
+    w = np.hanning(fft_size)
+    rows = []
+    for start in range(0, len(x) - fft_size, hopsamp):
+        rows.append(np.fft.rfft(w * x[start:start + fft_size]))
+    return np.array(rows)
+
+
+# --------------------------------------------------------------------------
+# a-5  istft_for_reconstruction           audio_utilities.py:95-114
+# --------------------------------------------------------------------------
+def istft_loop(X, fft_size, hopsamp):
+    """Loop form, float64.  x = zeros(T*hop + N); x[i:i+N] += w*real(irfft(X[n]))
+    in frame order, NO window-sum normalisation (audio_utilities.py:108-114)."""
+    fft_size = int(fft_size)
+    hopsamp = int(hopsamp)
+    w = np.hanning(fft_size)
+    n_frames = X.shape[0]
+    total = int(n_frames * hopsamp + fft_size)
+    x = np.zeros(total)
+    for n, start in enumerate(range(0, len(x) - fft_size, hopsamp)):
+        x[start:start + fft_size] += w * np.real(np.fft.irfft(X[n]))
+    return x
+
+
+# --------------------------------------------------------------------------
+# a-3 / a-6  reconstruct_signal_griffin_lim   audio_utilities.py:154-188
+# --------------------------------------------------------------------------
+def griffin_lim_loop(magnitude_spectrogram, fft_size, hopsamp, iterations, x0=None):
+    """Line-faithful loop form (float64) including the dead per-iteration RMSE
+    computed with the Python builtin ``sum`` (audio_utilities.py:186) -- this is
+    the form timed as the CPU baseline, because it is what the reference does.
+
+    x0=None draws the start signal from numpy's global legacy RNG exactly like
+    audio_utilities.py:176; passing x0 replaces only that draw."""
+    n_frames = magnitude_spectrogram.shape[0]
+    total = int(n_frames * hopsamp + fft_size)
+    if x0 is None:
+        x = np.random.randn(total)
+    else:
+        x = np.asarray(x0, dtype=np.float64)
+        assert x.shape == (total,)
+    left = iterations
+    while left > 0:
+        left -= 1
+        S = stft_loop(x, fft_size, hopsamp)
+        theta = np.angle(S)
+        proposal = magnitude_spectrogram * np.exp(1.0j * theta)
+        prev = x
+        x = istft_loop(proposal, fft_size, hopsamp)
+        _rmse = np.sqrt(sum((x - prev) ** 2) / x.size)  # dead value, kept for timing fidelity
+    return x
+
+
+# --------------------------------------------------------------------------
+# Vectorised forms (same maths, used where the loop form would be too slow
+# for a unit test).  Checked against the loop forms in tests/.
+# --------------------------------------------------------------------------
+def frame_starts(total_len, fft_size, hopsamp):
+    return np.arange(0, total_len - int(fft_size), int(hopsamp))
+
+
+def stft_vec(x, fft_size, hopsamp, dtype=np.float64):
+    fft_size = int(fft_size)
+    x = np.asarray(x, dtype=dtype)
+    w = np.hanning(fft_size).astype(dtype)
+    starts = frame_starts(len(x), fft_size, hopsamp)
+    idx = starts[:, None] + np.arange(fft_size)[None, :]
+    return np.fft.rfft(w[None, :] * x[idx], axis=1)
+
+
+def istft_vec(X, fft_size, hopsamp, dtype=np.float64):
+    fft_size = int(fft_size)
+    hopsamp = int(hopsamp)
+    w = np.hanning(fft_size).astype(dtype)
+    n_frames = X.shape[0]
+    total = n_frames * hopsamp + fft_size
+    frames = (w[None, :] * np.fft.irfft(X, n=fft_size, axis=1)).astype(dtype)
+    x = np.zeros(total, dtype=dtype)
+    # frame order is preserved so the floating-point summation order matches
+    # the reference's `+=` loop
+    for n in range(n_frames):
+        x[n * hopsamp:n * hopsamp + fft_size] += frames[n]
+    return x
+
+
+def project(S, mag):
+    """audio_utilities.py:181-183: mag * exp(1j*angle(S)); angle(0) == 0."""
+    return mag * np.exp(1.0j * np.angle(S))
+
+
+def griffin_lim_vec(mag, fft_size, hopsamp, iterations, x0):
+    x = np.asarray(x0, dtype=np.float64)
+    for _ in range(int(iterations)):
+        x = istft_vec(project(stft_vec(x, fft_size, hopsamp), mag), fft_size, hopsamp)
+    return x
+
+
+def spectral_convergence(x, mag, fft_size, hopsamp, fit_gain=True):
+    """|| |STFT(x)|/c - mag ||_F / || mag ||_F  (SURVEY 8d parity gate).  The
+    reference ISTFT applies no window-sum normalisation, so x carries a gain of
+    about sum(w^2)/hop; c is the least-squares scalar that removes it."""
+    S = np.abs(stft_vec(x, fft_size, hopsamp))
+    mag = np.asarray(mag, dtype=np.float64)
+    c = float(np.sum(S * mag) / max(np.sum(S * S), 1e-300)) if fit_gain else 1.0
+    return float(np.linalg.norm(S * c - mag) / np.linalg.norm(mag))
+
+
+# --------------------------------------------------------------------------
+# a-1  librosa.filters.mel call site     griffin_lim.py:13-14   (UNPINNED)
+# --------------------------------------------------------------------------
+def _hz_to_mel_slaney(f):
+    f = np.asanyarray(f, dtype=np.float64)
+    f_sp = 200.0 / 3
+    mels = f / f_sp
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = np.log(6.4) / 27.0
+    with np.errstate(divide="ignore", invalid="ignore"):
+        log_part = min_log_mel + np.log(np.maximum(f, 1e-300) / min_log_hz) / logstep
+    return np.where(f >= min_log_hz, log_part, mels)
+
+
+def _mel_to_hz_slaney(m):
+    m = np.asanyarray(m, dtype=np.float64)
+    f_sp = 200.0 / 3
+    freqs = f_sp * m
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = np.log(6.4) / 27.0
+    return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), freqs)
+
+
+def mel_filterbank_slaney(sr, n_fft, n_mels=80, fmin=0.0, fmax=None):
+    """(n_mels, 1+n_fft//2) float32 triangular filterbank, Slaney mel scale,
+    Slaney area normalisation -- librosa.filters.mel(htk=False, norm='slaney')
+    as documented.  PARITY UNPINNED (see module docstring)."""
+    if fmax is None:
+        fmax = sr / 2.0
+    n_bins = 1 + n_fft // 2
+    fftfreqs = np.linspace(0.0, sr / 2.0, n_bins)
+    mel_pts = np.linspace(_hz_to_mel_slaney(fmin), _hz_to_mel_slaney(fmax), n_mels + 2)
+    mel_f = _mel_to_hz_slaney(mel_pts)
+    fdiff = np.diff(mel_f)
+    ramps = mel_f[:, None] - fftfreqs[None, :]
+    weights = np.zeros((n_mels, n_bins), dtype=np.float64)
+    for i in range(n_mels):
+        lower = -ramps[i] / fdiff[i]
+        upper = ramps[i + 2] / fdiff[i + 1]
+        weights[i] = np.maximum(0.0, np.minimum(lower, upper))
+    enorm = 2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels])
+    weights *= enorm[:, None]
+    return weights.astype(np.float32)
+
+
+# --------------------------------------------------------------------------
+# a-2  save_mel_to_wav (everything but the file write)   griffin_lim.py:17-35
+# --------------------------------------------------------------------------
+def mel_to_linear(filterbank, mel):
+    """griffin_lim.py:18-19: np.dot(filterbank.T, mel).T -> (T, F)."""
+    return np.dot(filterbank.T, mel).T
+
+
+def peak_normalise(x):
+    """griffin_lim.py:27-29: divide by max|x| only when it exceeds 1."""
+    peak = np.max(np.abs(x))
+    if peak > 1.0:
+        return x / peak
+    return x
+
+
+# --------------------------------------------------------------------------
+# a-7  save_audio_to_file sample conversion   audio_utilities.py:202-210
+# --------------------------------------------------------------------------
+def pcm16_from_float(x):
+    """assert max|x| <= 1; x /= max|x|; x *= 32767; int(round(.)) per sample.
+    Python's round() is round-half-to-even == np.rint."""
+    x = np.array(x, dtype=np.float64, copy=True)
+    peak = np.max(np.abs(x))
+    assert peak <= 1.0, 'Input audio value is out of range. Should be in the range [-1.0, 1.0].'
+    x /= peak
+    x *= 32767.0
+    return np.rint(x).astype('<i2')

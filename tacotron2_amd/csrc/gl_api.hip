@@ -1,0 +1,205 @@
+// C-ABI of libgl_hip.so (see include/gl_hip.h): argument validation, plan
+// lifetime, and dispatch to the fused (gl_fast.hip) or generic (gl_generic.hip)
+// kernels.  Host code only; no kernels live here.
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "gl_internal.h"
+
+namespace {
+thread_local char g_err[512] = "";
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) return;
+        if (prev != dev && hipSetDevice(dev) != hipSuccess) return;
+        ok = true;
+    }
+    ~DeviceGuard() {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+
+bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+}  // namespace
+
+int gl_set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int gl_plan_alloc(gl_plan* p, void** ptr, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(ptr, bytes);
+    if (e != hipSuccess) {
+        *ptr = nullptr;
+        (void)hipGetLastError();
+        return gl_set_error(GL_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    }
+    p->bytes += (long long)bytes;
+    return 0;
+}
+
+extern "C" {
+
+int gl_version(void) { return 100; }
+
+const char* gl_last_error(void) { return g_err; }
+
+long long gl_signal_length(int n_fft, int hop, int frames) { return (long long)frames * hop + n_fft; }
+
+int gl_num_frames(int n_fft, int hop, long long len) {
+    if (hop < 1 || len <= n_fft) return 0;
+    return (int)((len - n_fft + hop - 1) / hop);  // len(range(0, len - N, H))
+}
+
+int gl_plan_create(int n_fft, int hop, int max_frames, int max_batch, int device, gl_plan** out) {
+    if (!out) return gl_set_error(GL_ERR_INVALID, "gl_plan_create: out is NULL");
+    *out = nullptr;
+    if (!is_pow2(n_fft) || n_fft < 64 || n_fft > 4096)
+        return gl_set_error(GL_ERR_INVALID, "n_fft must be a power of two in [64, 4096], got %d", n_fft);
+    if (hop < 1) return gl_set_error(GL_ERR_INVALID, "hop must be >= 1, got %d", hop);
+    if (max_frames < 1 || max_batch < 1 || max_batch > 65535)
+        return gl_set_error(GL_ERR_INVALID, "max_frames must be >= 1 and max_batch in [1, 65535] (got %d, %d)",
+                            max_frames, max_batch);
+    int ndev = 0;
+    GL_HIP_CHECK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev)
+        return gl_set_error(GL_ERR_INVALID, "device %d out of range (%d visible)", device, ndev);
+    DeviceGuard guard(device);
+    if (!guard.ok) return gl_set_error(GL_ERR_HIP, "cannot select device %d", device);
+
+    gl_plan* p = new (std::nothrow) gl_plan();
+    if (!p) return gl_set_error(GL_ERR_NOMEM, "host allocation failed");
+    memset(p, 0, sizeof(*p));
+    p->n_fft = n_fft;
+    p->hop = hop;
+    p->max_T = max_frames;
+    p->max_B = max_batch;
+    p->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) p->n_cu = prop.multiProcessorCount;
+    if (p->n_cu <= 0) p->n_cu = 256;
+
+    // np.hanning(N) = 0.5 - 0.5*cos(2*pi*n/(N-1))  (audio_utilities.py:88,108), in double
+    std::vector<float> win(n_fft);
+    std::vector<float2> tw(n_fft);
+    const double pi = 3.14159265358979323846;
+    for (int n = 0; n < n_fft; ++n) {
+        win[n] = (float)(0.5 - 0.5 * cos(2.0 * pi * n / (double)(n_fft - 1)));
+        double a = -2.0 * pi * n / (double)n_fft;
+        tw[n] = make_float2((float)cos(a), (float)sin(a));
+    }
+    int rc = gl_plan_alloc(p, (void**)&p->d_window, sizeof(float) * n_fft);
+    if (!rc) rc = gl_plan_alloc(p, (void**)&p->d_tw, sizeof(float2) * n_fft);
+    if (!rc) rc = gl_plan_alloc(p, (void**)&p->d_peaks, sizeof(unsigned) * (size_t)max_batch);
+    if (!rc) {
+        hipError_t e = hipMemcpy(p->d_window, win.data(), sizeof(float) * n_fft, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(p->d_tw, tw.data(), sizeof(float2) * n_fft, hipMemcpyHostToDevice);
+        if (e != hipSuccess) rc = gl_set_error(GL_ERR_HIP, "table upload failed: %s", hipGetErrorString(e));
+    }
+    if (rc) {
+        gl_plan_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return 0;
+}
+
+int gl_plan_destroy(gl_plan* p) {
+    if (!p) return 0;
+    DeviceGuard guard(p->device);
+    void* ptrs[] = {p->d_window, p->d_tw,     p->d_frames, p->d_xa,      p->d_xb,
+                    p->d_tail_a, p->d_tail_b, p->d_fast_tab, p->d_peaks};
+    for (void* q : ptrs)
+        if (q) (void)hipFree(q);
+    delete p;
+    return 0;
+}
+
+long long gl_plan_device_bytes(const gl_plan* p) { return p ? p->bytes : 0; }
+
+int gl_plan_set_path(gl_plan* p, int path) {
+    if (!p || path < 0 || path > 1) return gl_set_error(GL_ERR_INVALID, "gl_plan_set_path: bad argument");
+    p->path = path;
+    return 0;
+}
+
+static int check_call(const gl_plan* p, int B, int T, const char* who) {
+    if (!p) return gl_set_error(GL_ERR_INVALID, "%s: plan is NULL", who);
+    if (B < 1 || B > p->max_B) return gl_set_error(GL_ERR_INVALID, "%s: B=%d outside [1, %d]", who, B, p->max_B);
+    if (T < 1 || T > p->max_T) return gl_set_error(GL_ERR_INVALID, "%s: T=%d outside [1, %d]", who, T, p->max_T);
+    return 0;
+}
+
+static bool use_fast(const gl_plan* p) { return p->path == 0 && gl_fast_supported(p); }
+
+int gl_stft(gl_plan* p, const float* x, long long x_stride, float* S, int B, int T, void* stream) {
+    int rc = check_call(p, B, T, "gl_stft");
+    if (rc) return rc;
+    if (!x || !S) return gl_set_error(GL_ERR_INVALID, "gl_stft: NULL buffer");
+    if (x_stride < (long long)(T - 1) * p->hop + p->n_fft)
+        return gl_set_error(GL_ERR_INVALID, "gl_stft: x_stride %lld shorter than (T-1)*H+N", x_stride);
+    DeviceGuard guard(p->device);
+    hipStream_t st = (hipStream_t)stream;
+    return use_fast(p) ? gl_fast_stft(p, x, x_stride, S, B, T, st) : gl_generic_stft(p, x, x_stride, S, B, T, st);
+}
+
+int gl_istft(gl_plan* p, const float* S, float* y, int B, int T, void* stream) {
+    int rc = check_call(p, B, T, "gl_istft");
+    if (rc) return rc;
+    if (!S || !y) return gl_set_error(GL_ERR_INVALID, "gl_istft: NULL buffer");
+    DeviceGuard guard(p->device);
+    hipStream_t st = (hipStream_t)stream;
+    return use_fast(p) ? gl_fast_istft(p, S, y, B, T, st) : gl_generic_istft(p, S, y, B, T, st);
+}
+
+int gl_mel_to_mag(gl_plan* p, const float* filterbank, const float* mel, float* mag, int n_mels, int B, int T,
+                  void* stream) {
+    int rc = check_call(p, B, T, "gl_mel_to_mag");
+    if (rc) return rc;
+    if (!filterbank || !mel || !mag) return gl_set_error(GL_ERR_INVALID, "gl_mel_to_mag: NULL buffer");
+    if (n_mels < 1 || n_mels > 4096) return gl_set_error(GL_ERR_INVALID, "gl_mel_to_mag: n_mels=%d", n_mels);
+    DeviceGuard guard(p->device);
+    return gl_mel_launch(filterbank, mel, mag, n_mels, p->n_fft / 2 + 1, B, T, (hipStream_t)stream);
+}
+
+int gl_run(gl_plan* p, const float* mag, const float* x0, float* x_out, int iters, int B, int T, void* stream) {
+    int rc = check_call(p, B, T, "gl_run");
+    if (rc) return rc;
+    if (!mag || !x0 || !x_out) return gl_set_error(GL_ERR_INVALID, "gl_run: NULL buffer");
+    if (iters < 0) return gl_set_error(GL_ERR_INVALID, "gl_run: iters=%d", iters);
+    DeviceGuard guard(p->device);
+    hipStream_t st = (hipStream_t)stream;
+    if (iters == 0) return gl_copy_rows(x_out, x0, (long long)B * gl_len(p->n_fft, p->hop, T), st);
+    return use_fast(p) ? gl_fast_run(p, mag, x0, x_out, iters, B, T, st)
+                       : gl_generic_run(p, mag, x0, x_out, iters, B, T, st);
+}
+
+int gl_randn(float* out, long long n, uint64_t seed, void* stream) {
+    if (!out || n < 0) return gl_set_error(GL_ERR_INVALID, "gl_randn: bad argument");
+    if (n == 0) return 0;
+    return gl_randn_launch(out, n, seed, (hipStream_t)stream);
+}
+
+int gl_peak_normalise(gl_plan* p, float* x, long long row_stride, long long len, float* peaks, int mode, int B,
+                      void* stream) {
+    if (!p || !x) return gl_set_error(GL_ERR_INVALID, "gl_peak_normalise: NULL argument");
+    if (B < 1 || B > p->max_B) return gl_set_error(GL_ERR_INVALID, "gl_peak_normalise: B=%d outside [1, %d]", B, p->max_B);
+    if (len < 1 || row_stride < len || (mode != 0 && mode != 1))
+        return gl_set_error(GL_ERR_INVALID, "gl_peak_normalise: bad len/stride/mode");
+    DeviceGuard guard(p->device);
+    return gl_peak_launch(p, x, row_stride, len, peaks, mode, B, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,89 @@
+// Internal declarations shared by the translation units of libgl_hip.so.
+// gfx950 (MI355X) only; see include/gl_hip.h for the public C-ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/gl_hip.h"
+
+struct gl_plan {
+    int n_fft;        // N
+    int hop;          // H
+    int max_T;
+    int max_B;
+    int device;
+    int path;         // 0 auto, 1 generic
+    int n_cu;         // compute units of the device
+    float* d_window;  // [N]   symmetric Hann
+    float2* d_tw;     // [N]   exp(-2*pi*i*k/N)
+    float* d_frames;  // generic path scratch [max_B][max_T][N] (lazy)
+    float* d_xa;      // ping-pong signal buffers [max_B][L] (lazy)
+    float* d_xb;
+    float* d_tail_a;  // fused path: per-run partial-sum tails (lazy)
+    float* d_tail_b;
+    float* d_fast_tab;  // fused path constant tables (lazy)
+    unsigned* d_peaks;  // [max_B] bit patterns of max|x|
+    long long bytes;
+};
+
+// error plumbing (gl_api.hip)
+int gl_set_error(int code, const char* fmt, ...);
+#define GL_HIP_CHECK(expr)                                                            \
+    do {                                                                              \
+        hipError_t e_ = (expr);                                                       \
+        if (e_ != hipSuccess)                                                         \
+            return gl_set_error(GL_ERR_HIP, "%s failed: %s (%s:%d)", #expr,           \
+                                hipGetErrorString(e_), __FILE__, __LINE__);           \
+    } while (0)
+
+static inline long long gl_len(int N, int H, int T) { return (long long)T * H + N; }
+int gl_plan_alloc(gl_plan* p, void** ptr, size_t bytes);  // tracked hipMalloc
+
+// ---- generic (any power-of-two N) kernels: gl_generic.hip ---------------------
+int gl_generic_stft(gl_plan* p, const float* x, long long x_stride, float* S, int B, int T, hipStream_t st);
+int gl_generic_istft(gl_plan* p, const float* S, float* y, int B, int T, hipStream_t st);
+int gl_generic_run(gl_plan* p, const float* mag, const float* x0, float* x_out, int iters, int B, int T,
+                   hipStream_t st);
+
+// ---- fused wave-per-frame kernels: gl_fast.hip -----------------------------------
+bool gl_fast_supported(const gl_plan* p);
+int gl_fast_stft(gl_plan* p, const float* x, long long x_stride, float* S, int B, int T, hipStream_t st);
+int gl_fast_istft(gl_plan* p, const float* S, float* y, int B, int T, hipStream_t st);
+int gl_fast_run(gl_plan* p, const float* mag, const float* x0, float* x_out, int iters, int B, int T,
+                hipStream_t st);
+
+// ---- mel inversion (MFMA): gl_mel.hip ---------------------------------------------
+int gl_mel_launch(const float* fb, const float* mel, float* mag, int n_mels, int F, int B, int T, hipStream_t st);
+
+// ---- misc: gl_misc.hip -------------------------------------------------------------
+int gl_randn_launch(float* out, long long n, uint64_t seed, hipStream_t st);
+int gl_peak_launch(gl_plan* p, float* x, long long row_stride, long long len, float* peaks, int mode, int B,
+                   hipStream_t st);
+int gl_copy_rows(float* dst, const float* src, long long n, hipStream_t st);
+
+// ---- small complex helpers ------------------------------------------------------------
+__device__ __forceinline__ float2 c_add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 c_sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 c_mul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 c_mulc(float2 a, float2 b) {  // a * conj(b)
+    return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+__device__ __forceinline__ float2 c_conj(float2 a) { return make_float2(a.x, -a.y); }
+
+// Magnitude projection, audio_utilities.py:181-183: mag * exp(1j*angle(X));
+// np.angle(0) == 0 so a zero bin becomes (mag, 0).
+// Fused form X * mag * rsqrt(|X|^2); bins whose |X|^2 would be subnormal in fp32
+// are rescaled by 2^60 first so the phase of tiny-but-nonzero bins is kept.
+__device__ __forceinline__ float2 gl_project(float2 X, float m) {
+    float r2 = X.x * X.x + X.y * X.y;
+    if (__builtin_expect(r2 < 1e-30f, 0)) {
+        X.x *= 1.152921504606846976e18f;
+        X.y *= 1.152921504606846976e18f;
+        r2 = X.x * X.x + X.y * X.y;
+        if (!(r2 > 0.0f)) return make_float2(m, 0.0f);
+    }
+    float s = m * rsqrtf(r2);
+    return make_float2(X.x * s, X.y * s);
+}

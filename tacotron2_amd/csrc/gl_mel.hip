@@ -1,0 +1,91 @@
+// Mel -> linear-frequency inversion on the matrix cores (gfx950 fp32-input MFMA).
+//
+// Replaces griffin_lim.py:18-19:   np.dot(filterbank.T, mel).T
+//     mag[b][t][f] = sum_m mel[b][m][t] * filterbank[m][f]
+// i.e. C[T x F] = A[T x K] * Bm[K x F] with A[t][m] = mel[b][m][t] (contiguous in t)
+// and Bm = the filterbank as stored (contiguous in f); K = n_mels (80).
+//
+// v_mfma_f32_32x32x2_f32: lane l supplies A[i = l&31][k = l>>5] and
+// B[k = l>>5][j = l&31]; the accumulator holds col = l&31,
+// row = (reg&3) + 8*(reg>>2) + 4*(l>>5).  With i = t and j = f both operand loads
+// and the C stores are contiguous across lanes, so no LDS staging is needed; the
+// output is written directly in the (B, T, F) row-major layout the Griffin-Lim
+// kernels read.  The result is bit-for-bit an fp32 fma chain over m = 0..K-1.
+#include "gl_internal.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kTileT = 32;      // rows (t) per wave
+constexpr int kTileF = 128;     // cols (f) per wave: 4 accumulators of 32
+constexpr int kWaves = 4;       // waves per workgroup, stacked along t
+
+__global__ void __launch_bounds__(64 * kWaves) k_mel_to_mag(const float* __restrict__ fb,
+                                                            const float* __restrict__ mel,
+                                                            float* __restrict__ mag, int K, int F, int T) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int b = blockIdx.z;
+    const int t0 = (blockIdx.y * kWaves + wave) * kTileT;
+    const int f0 = blockIdx.x * kTileF;
+    if (t0 >= T) return;  // wave-uniform
+
+    const int li = lane & 31;
+    const int lk = lane >> 5;
+    const int t = t0 + li;
+    const bool t_ok = t < T;
+    const float* a_ptr = mel + (long long)b * K * T + (t_ok ? t : 0);
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+
+    bool f_ok[4];
+    int fidx[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int f = f0 + 32 * j + li;
+        f_ok[j] = f < F;
+        fidx[j] = f_ok[j] ? f : 0;
+    }
+
+    for (int k0 = 0; k0 < K; k0 += 2) {
+        const int k = k0 + lk;
+        const bool k_ok = k < K;
+        const int kk = k_ok ? k : 0;
+        float a = a_ptr[(long long)kk * T];
+        a = (k_ok && t_ok) ? a : 0.0f;
+        float bv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = fb[(long long)kk * F + fidx[j]];
+            bv[j] = (k_ok && f_ok[j]) ? v : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[j], acc[j], 0, 0, 0);
+    }
+
+    float* out = mag + (long long)b * T * F;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int f = f0 + 32 * j + li;
+        if (f >= F) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = t0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            if (row < T) out[(long long)row * F + f] = acc[j][r];
+        }
+    }
+}
+
+}  // namespace
+
+int gl_mel_launch(const float* fb, const float* mel, float* mag, int n_mels, int F, int B, int T, hipStream_t st) {
+    dim3 grid((F + kTileF - 1) / kTileF, (T + kTileT * kWaves - 1) / (kTileT * kWaves), B);
+    hipLaunchKernelGGL(k_mel_to_mag, grid, dim3(64 * kWaves), 0, st, fb, mel, mag, n_mels, F, T);
+    GL_HIP_CHECK(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,115 @@
+// Small streaming kernels around the Griffin-Lim loop: device RNG for the start
+// signal, per-utterance peak normalisation, row copy.
+#include "gl_internal.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+// ---- Philox4x32-10 -----------------------------------------------------------------
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+    uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+    uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+__device__ __forceinline__ float u01(uint32_t r) {  // (0, 1]
+    return ((float)(r >> 8) + 1.0f) * (1.0f / 16777216.0f);
+}
+
+// Stands in for np.random.randn(len_samples) (audio_utilities.py:176) in
+// throughput runs; four normals per counter value.
+__global__ void __launch_bounds__(kThreads) k_randn(float* __restrict__ out, long long n, uint64_t seed) {
+    long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long nq = (n + 3) >> 2;
+    for (; q < nq; q += (long long)gridDim.x * blockDim.x) {
+        uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), 0u, 0u};
+        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            philox_round(c, k0, k1);
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+        float r0 = sqrtf(-2.0f * __logf(u01(c[0])));
+        float r1 = sqrtf(-2.0f * __logf(u01(c[2])));
+        float s0, c0, s1, c1;
+        __sincosf(6.283185307179586f * u01(c[1]), &s0, &c0);
+        __sincosf(6.283185307179586f * u01(c[3]), &s1, &c1);
+        float v[4] = {r0 * c0, r0 * s0, r1 * c1, r1 * s1};
+        long long base = q << 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (base + j < n) out[base + j] = v[j];
+    }
+}
+
+// ---- peak normalisation (griffin_lim.py:27-29) ---------------------------------------
+__global__ void __launch_bounds__(kThreads) k_absmax(const float* __restrict__ x, long long row_stride,
+                                                     long long len, unsigned* __restrict__ peaks) {
+    const int b = blockIdx.y;
+    const float* row = x + (long long)b * row_stride;
+    float m = 0.0f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < len;
+         i += (long long)gridDim.x * blockDim.x)
+        m = fmaxf(m, fabsf(row[i]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    __shared__ float wmax[kThreads / 64];
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float r = wmax[0];
+        for (int w = 1; w < kThreads / 64; ++w) r = fmaxf(r, wmax[w]);
+        // non-negative floats order like their bit patterns
+        atomicMax(&peaks[b], __float_as_uint(r));
+    }
+}
+
+__global__ void __launch_bounds__(kThreads) k_peak_scale(float* __restrict__ x, long long row_stride, long long len,
+                                                         const unsigned* __restrict__ peaks,
+                                                         float* __restrict__ peaks_out, int mode) {
+    const int b = blockIdx.y;
+    const float peak = __uint_as_float(peaks[b]);
+    if (peaks_out && blockIdx.x == 0 && threadIdx.x == 0) peaks_out[b] = peak;
+    const bool scale = (mode == 0) ? (peak > 1.0f) : (peak > 0.0f);
+    if (!scale) return;
+    float* row = x + (long long)b * row_stride;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < len;
+         i += (long long)gridDim.x * blockDim.x)
+        row[i] = row[i] / peak;
+}
+
+}  // namespace
+
+int gl_randn_launch(float* out, long long n, uint64_t seed, hipStream_t st) {
+    long long nq = (n + 3) >> 2;
+    long long blocks = (nq + kThreads - 1) / kThreads;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_randn, dim3((unsigned)blocks), dim3(kThreads), 0, st, out, n, seed);
+    GL_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int gl_peak_launch(gl_plan* p, float* x, long long row_stride, long long len, float* peaks, int mode, int B,
+                   hipStream_t st) {
+    GL_HIP_CHECK(hipMemsetAsync(p->d_peaks, 0, sizeof(unsigned) * (size_t)B, st));
+    long long blocks = (len + kThreads * 8 - 1) / (kThreads * 8);
+    if (blocks > 64) blocks = 64;
+    if (blocks < 1) blocks = 1;
+    dim3 grid((unsigned)blocks, B);
+    hipLaunchKernelGGL(k_absmax, grid, dim3(kThreads), 0, st, x, row_stride, len, p->d_peaks);
+    GL_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_peak_scale, grid, dim3(kThreads), 0, st, x, row_stride, len, p->d_peaks, peaks, mode);
+    GL_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int gl_copy_rows(float* dst, const float* src, long long n, hipStream_t st) {
+    if (dst == src || n <= 0) return 0;
+    GL_HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return 0;
+}

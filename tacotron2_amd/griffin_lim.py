@@ -1,0 +1,110 @@
+"""MI355X drop-in for the reference's ``griffin_lim.py``.
+
+``save_mel_to_wav(mel_spectrogram, filename='out')`` keeps the reference
+signature and behaviour (griffin_lim.py:17-35): mel -> linear magnitude with the
+TRANSPOSE of the mel filterbank (not a pseudo-inverse), Griffin-Lim with the
+``params`` geometry, peak-normalise only if max|x| > 1, write
+``<audio_out_path>/<filename>.wav``, return the (F, T) linear magnitude.
+The contraction runs on MFMA (gl_mel_to_mag) and the loop on the fused HIP
+kernels (gl_run); only the 16-bit WAV encode stays on the host.
+"""
+import os
+from os.path import join
+
+import numpy as np
+import torch
+
+from . import audio_utilities, filters
+from .plan import get_plan, _require_gpu
+
+try:  # the caller's own configuration module wins (infer.py does `import params`)
+    import params as _params
+    for _name in ("sampling_rate", "n_fft", "n_mel_channels", "f_min", "f_max", "frame_hop",
+                  "griffin_lim_iters", "audio_out_path"):
+        getattr(_params, _name)
+except (ImportError, AttributeError):
+    from . import params as _params
+params = _params
+
+# griffin_lim.py:13-14 -- module-level filterbank, shape (n_mels, 1 + n_fft//2), float32
+filterbank = filters.mel(sr=params.sampling_rate, n_fft=params.n_fft, n_mels=params.n_mel_channels,
+                         fmin=params.f_min, fmax=params.f_max)
+
+_fb_cache = {}
+
+
+def _device_filterbank(fb, dev):
+    key = (id(fb), dev.index)
+    hit = _fb_cache.get(key)
+    if hit is not None and hit[0] is fb:
+        return hit[1]
+    t = torch.from_numpy(np.ascontiguousarray(fb, dtype=np.float32)).to(dev)
+    _fb_cache[key] = (fb, t)
+    return t
+
+
+def mel_to_audio(mel_spectrogram, *, basis=None, n_fft=None, hop=None, iterations=None, x_init=None, seed=None,
+                 rng="numpy", normalize="reference", device=None):
+    """Batched core of save_mel_to_wav, everything on the GPU.
+
+    mel_spectrogram: (n_mels, T) or (B, n_mels, T), numpy or torch (linear-amplitude
+    mel, i.e. after exp, infer.py:27).  basis: (F, n_mels) inversion basis; default
+    ``filterbank.T`` like griffin_lim.py:18.  normalize: 'reference' (divide by the
+    peak only when it exceeds 1, griffin_lim.py:27-29), 'peak' (always) or None.
+    Returns (waveforms (B, L) fp32 torch on device, magnitude (B, T, F) fp32 torch)."""
+    n_fft = int(params.n_fft if n_fft is None else n_fft)
+    hop = int(params.frame_hop if hop is None else hop)
+    iterations = int(params.griffin_lim_iters if iterations is None else iterations)
+    dev = audio_utilities._pick_device(device, mel_spectrogram)
+    mel, _ = audio_utilities._to_device(mel_spectrogram, dev, torch.float32)
+    if mel.dim() == 2:
+        mel = mel[None]
+    if mel.dim() != 3:
+        raise ValueError("mel_spectrogram must be (n_mels, T) or (B, n_mels, T)")
+    B, n_mels, T = mel.shape
+    if basis is None:
+        if n_fft != params.n_fft:
+            fb = filters.mel(sr=params.sampling_rate, n_fft=n_fft, n_mels=n_mels, fmin=params.f_min,
+                             fmax=params.f_max)
+            fb_dev = torch.from_numpy(fb).to(dev)
+        else:
+            fb_dev = _device_filterbank(filterbank, dev)
+    else:
+        b, _ = audio_utilities._to_device(basis, dev, torch.float32)
+        fb_dev = b.t().contiguous()          # kernel wants (n_mels, F)
+    if tuple(fb_dev.shape) != (n_mels, n_fft // 2 + 1):
+        raise ValueError(f"basis/filterbank shape {tuple(fb_dev.shape)} does not match "
+                         f"({n_mels}, {n_fft // 2 + 1})")
+    plan = get_plan(n_fft, hop, T, B, dev)
+    mag = plan.mel_to_mag(fb_dev, mel)                       # griffin_lim.py:18-19
+    L = plan.signal_length(T)
+    x0 = audio_utilities._start_signal(B, L, x_init, seed, rng, plan, dev)
+    x = plan.run(mag, x0, iterations, out=x0)                # griffin_lim.py:23-24
+    if normalize == "reference":
+        plan.peak_normalise(x, mode=0)                       # griffin_lim.py:27-29
+    elif normalize == "peak":
+        plan.peak_normalise(x, mode=1)
+    elif normalize is not None:
+        raise ValueError("normalize must be 'reference', 'peak' or None")
+    return x, mag
+
+
+def save_mel_to_wav(mel_spectrogram, filename='out', *, basis=None, iterations=None, x_init=None, seed=None,
+                    rng="numpy", device=None, write_wav=True):
+    """Reference entry point (griffin_lim.py:17-35); see the module docstring.
+
+    mel_spectrogram: (n_mels, T) array (any strides; infer.py:28 passes a transposed view)."""
+    if np.ndim(mel_spectrogram) != 2:
+        raise ValueError("save_mel_to_wav takes one (n_mels, T) spectrogram; use mel_to_audio for batches")
+    x, mag = mel_to_audio(mel_spectrogram, basis=basis, iterations=iterations, x_init=x_init, seed=seed, rng=rng,
+                          normalize="reference", device=device)
+    if write_wav:
+        out_dir = params.audio_out_path
+        os.makedirs(out_dir, exist_ok=True)
+        audio_utilities.save_audio_to_file(x[0].cpu().numpy().astype(np.float64), params.sampling_rate,
+                                           outfile=join(out_dir, filename + '.wav'))
+    # griffin_lim.py:35 returns stft_modified.T == the (F, T) linear magnitude
+    lin = mag[0].t()
+    if isinstance(mel_spectrogram, torch.Tensor):
+        return lin
+    return lin.cpu().numpy()

@@ -1,0 +1,168 @@
+"""Plan objects: one (n_fft, hop, device) geometry bound to libgl_hip scratch.
+
+PyTorch-ROCm is used only for device memory and streams; all compute goes
+through the C-ABI in include/gl_hip.h.
+"""
+import ctypes
+import threading
+
+import torch
+
+from . import _lib
+
+
+def _stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _require_gpu(device):
+    if not torch.cuda.is_available():
+        raise RuntimeError("tacotron2_amd needs a ROCm GPU (MI355X / gfx950): torch.cuda.is_available() is False "
+                           "and there is no CPU fallback for the Griffin-Lim path")
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.type != "cuda":
+        raise ValueError(f"device must be a cuda (ROCm) device, got {dev}")
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    return dev
+
+
+class Plan:
+    """Owns a gl_plan handle.  Methods take/return fp32 torch tensors on the plan's device."""
+
+    def __init__(self, n_fft, hop, max_frames, max_batch, device=None):
+        self.device = _require_gpu(device)
+        self.n_fft = int(n_fft)
+        self.hop = int(hop)
+        self.max_frames = int(max_frames)
+        self.max_batch = int(max_batch)
+        self.n_bins = self.n_fft // 2 + 1
+        self._h = ctypes.c_void_p()
+        self._lib = _lib.lib()
+        _lib.check(self._lib.gl_plan_create(self.n_fft, self.hop, self.max_frames, self.max_batch,
+                                            self.device.index, ctypes.byref(self._h)), "gl_plan_create")
+
+    # -- lifetime ---------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.gl_plan_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers ------------------------------------------------------------------
+    def signal_length(self, frames):
+        return int(frames) * self.hop + self.n_fft
+
+    def device_bytes(self):
+        return int(self._lib.gl_plan_device_bytes(self._h))
+
+    def set_path(self, path):
+        """0 = auto (fused kernels where available), 1 = force the generic kernels."""
+        _lib.check(self._lib.gl_plan_set_path(self._h, int(path)), "gl_plan_set_path")
+
+    def _f32(self, t, shape=None):
+        if t.device != self.device or t.dtype != torch.float32 or not t.is_contiguous():
+            raise ValueError("expected a contiguous float32 tensor on %s" % (self.device,))
+        if shape is not None and tuple(t.shape) != tuple(shape):
+            raise ValueError(f"expected shape {tuple(shape)}, got {tuple(t.shape)}")
+        return ctypes.c_void_p(t.data_ptr())
+
+    # -- kernels --------------------------------------------------------------------
+    def stft(self, x, frames=None):
+        """x (B, Lx) -> complex64 (B, T, F).  T defaults to len(range(0, Lx - N, H))."""
+        B, Lx = x.shape
+        T = self._lib.gl_num_frames(self.n_fft, self.hop, Lx) if frames is None else int(frames)
+        if T < 1:
+            return torch.empty((B, 0, self.n_bins), dtype=torch.complex64, device=self.device)
+        S = torch.empty((B, T, self.n_bins, 2), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.gl_stft(self._h, self._f32(x), Lx, self._f32(S), B, T,
+                                         _stream_ptr(self.device)), "gl_stft")
+        return torch.view_as_complex(S)
+
+    def istft(self, S):
+        """complex64 (B, T, F) -> (B, T*H+N) fp32."""
+        if S.dtype != torch.complex64:
+            raise ValueError("expected complex64")
+        Sr = torch.view_as_real(S.contiguous())
+        B, T, F, _ = Sr.shape
+        if F != self.n_bins:
+            raise ValueError(f"expected {self.n_bins} bins, got {F}")
+        y = torch.empty((B, self.signal_length(T)), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.gl_istft(self._h, self._f32(Sr), self._f32(y), B, T,
+                                          _stream_ptr(self.device)), "gl_istft")
+        return y
+
+    def mel_to_mag(self, filterbank, mel, out=None):
+        """filterbank (n_mels, F), mel (B, n_mels, T) -> mag (B, T, F)."""
+        B, n_mels, T = mel.shape
+        if out is None:
+            out = torch.empty((B, T, self.n_bins), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.gl_mel_to_mag(self._h, self._f32(filterbank, (n_mels, self.n_bins)),
+                                               self._f32(mel), self._f32(out, (B, T, self.n_bins)), n_mels, B, T,
+                                               _stream_ptr(self.device)), "gl_mel_to_mag")
+        return out
+
+    def run(self, mag, x0, iterations, out=None):
+        """mag (B, T, F), x0 (B, L) -> x (B, L) after `iterations` Griffin-Lim iterations."""
+        B, T, F = mag.shape
+        if F != self.n_bins:
+            raise ValueError(f"expected {self.n_bins} bins, got {F}")
+        L = self.signal_length(T)
+        if out is None:
+            out = torch.empty((B, L), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.gl_run(self._h, self._f32(mag), self._f32(x0, (B, L)), self._f32(out, (B, L)),
+                                        int(iterations), B, T, _stream_ptr(self.device)), "gl_run")
+        return out
+
+    def randn(self, shape, seed):
+        out = torch.empty(shape, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.gl_randn(self._f32(out), out.numel(), ctypes.c_uint64(int(seed) & (2**64 - 1)),
+                                          _stream_ptr(self.device)), "gl_randn")
+        return out
+
+    def peak_normalise(self, x, mode=0):
+        """In place on x (B, L); returns the per-row peaks (B,) before scaling."""
+        B, L = x.shape
+        peaks = torch.empty((B,), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.gl_peak_normalise(self._h, self._f32(x), L, L, self._f32(peaks), int(mode), B,
+                                                   _stream_ptr(self.device)), "gl_peak_normalise")
+        return peaks
+
+
+_cache = {}
+_cache_lock = threading.Lock()
+
+
+def get_plan(n_fft, hop, frames, batch, device=None):
+    """Cached plan for (n_fft, hop, device), regrown when frames/batch exceed its bounds."""
+    dev = _require_gpu(device)
+    key = (int(n_fft), int(hop), dev.index)
+    with _cache_lock:
+        p = _cache.get(key)
+        if p is None or p.max_frames < frames or p.max_batch < batch:
+            mf = max(int(frames), p.max_frames if p else 0)
+            mb = max(int(batch), p.max_batch if p else 0)
+            if p is not None:
+                torch.cuda.synchronize(dev)
+                p.close()
+            p = Plan(n_fft, hop, mf, mb, dev)
+            _cache[key] = p
+        return p
+
+
+def clear_plans():
+    with _cache_lock:
+        for p in _cache.values():
+            p.close()
+        _cache.clear()

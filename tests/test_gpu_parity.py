@@ -1,0 +1,280 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the golden vectors
+captured from the reference and against the CPU oracle on the same seeded inputs.
+
+Tolerances (north_star): fp32 kernels vs the float64 reference, max-abs sample
+error <= 1e-3 of the waveform peak and spectral-convergence delta <= 1e-3 after
+Griffin-Lim; single transforms are held to 2e-5 of the peak.
+"""
+import numpy as np
+import pytest
+import torch
+
+import gl_oracle as orc
+from tacotron2_amd import audio_utilities as au
+from tacotron2_amd import griffin_lim, filters
+from tacotron2_amd.plan import Plan, get_plan
+
+pytestmark = pytest.mark.gpu
+
+GEOMS = ["64_16", "256_100", "1024_275", "2048_256"]
+TOL_TRANSFORM = 2e-5     # single STFT / ISTFT, relative to peak
+TOL_GL = 1e-3            # after Griffin-Lim iterations, relative to peak (north_star)
+PATHS = [0, 1]           # 0 = auto (fused where available), 1 = generic kernels
+
+
+def peak_err(a, b):
+    a = np.asarray(a)
+    b = np.asarray(b)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-30))
+
+
+@pytest.fixture(autouse=True)
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    yield
+    torch.cuda.synchronize()
+
+
+def _plan(N, H, T, B, path):
+    p = Plan(N, H, T, B)
+    p.set_path(path)
+    return p
+
+
+# ---- a-4 -------------------------------------------------------------------------------
+@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("g", GEOMS)
+def test_stft_golden(golden, g, path):
+    d = golden("stft_" + g)
+    N, H = int(d["fft_size"]), int(d["hop"])
+    x = torch.from_numpy(d["x"].astype(np.float32)).cuda()[None]
+    p = _plan(N, H, d["S"].shape[0], 1, path)
+    S = p.stft(x)[0].cpu().numpy()
+    assert S.shape == d["S"].shape
+    assert peak_err(S, d["S"]) <= TOL_TRANSFORM
+    # DC and Nyquist bins of a real transform carry no imaginary part
+    assert np.all(S[:, 0].imag == 0) and np.all(S[:, -1].imag == 0)
+    p.close()
+
+
+def test_stft_public_api(golden):
+    d = golden("stft_1024_275")
+    S = au.stft_for_reconstruction(d["x"], 1024, 275)
+    assert S.dtype == np.complex128 and S.shape == d["S"].shape
+    assert peak_err(S, d["S"]) <= TOL_TRANSFORM
+    # frame-count rule incl. the exclusive range end (audio_utilities.py:92)
+    for extra in (0, 1, 274, 275, 276):
+        x = np.random.default_rng(extra).standard_normal(1024 + 275 * 3 + extra)
+        S = au.stft_for_reconstruction(x, 1024, 275)
+        assert S.shape[0] == len(range(0, len(x) - 1024, 275))
+        assert peak_err(S, orc.stft_vec(x, 1024, 275)) <= TOL_TRANSFORM
+    # too-short input: zero frames, like the reference's empty list comprehension
+    assert au.stft_for_reconstruction(np.zeros(1024), 1024, 275).shape[0] == 0
+    # torch in -> torch out, batch
+    xb = torch.randn(3, 5000, device="cuda")
+    Sb = au.stft_for_reconstruction(xb, 1024, 275)
+    assert Sb.is_cuda and Sb.dtype == torch.complex64 and Sb.shape == (3, len(range(0, 5000 - 1024, 275)), 513)
+    for i in range(3):
+        assert peak_err(Sb[i].cpu().numpy(), orc.stft_vec(xb[i].cpu().numpy().astype(np.float64), 1024, 275)) <= TOL_TRANSFORM
+
+
+# ---- a-5 -------------------------------------------------------------------------------
+@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("g", GEOMS)
+def test_istft_golden(golden, g, path):
+    d = golden("istft_" + g)
+    N, H = int(d["fft_size"]), int(d["hop"])
+    X = torch.from_numpy(d["X"].astype(np.complex64)).cuda()[None]
+    p = _plan(N, H, X.shape[1], 1, path)
+    y = p.istft(X)[0].cpu().numpy()
+    assert y.shape == d["y"].shape
+    assert peak_err(y, d["y"]) <= TOL_TRANSFORM
+    assert np.all(y[-H:] == 0.0)     # F4: last hop samples are exactly zero
+    p.close()
+
+
+def test_istft_public_api(golden):
+    d = golden("istft_2048_256")
+    y = au.istft_for_reconstruction(d["X"], 2048, 256)
+    assert y.dtype == np.float64 and y.shape == d["y"].shape
+    assert peak_err(y, d["y"]) <= TOL_TRANSFORM
+    with pytest.raises(ValueError):
+        au.istft_for_reconstruction(d["X"][:, :-1], 2048, 256)
+
+
+# ---- a-3 / a-6 -----------------------------------------------------------------------
+@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("name", ["gl_rand_64_16", "gl_rand_1024_275", "gl_rand_2048_256",
+                                  "gl_smooth_1024_275", "gl_smooth_2048_256", "gl_zero_bins"])
+def test_griffin_lim_golden(golden, name, path):
+    d = golden(name)
+    N, H = int(d["fft_size"]), int(d["hop"])
+    mag = torch.from_numpy(d["mag"]).cuda()[None]
+    x0 = torch.from_numpy(d["x0"].astype(np.float32)).cuda()[None]
+    p = _plan(N, H, mag.shape[1], 1, path)
+    for key in [k for k in d.files if k.startswith("y")]:
+        K = int(key[1:])
+        y = p.run(mag, x0, K)[0].cpu().numpy()
+        ref = d[key]
+        assert peak_err(y, ref) <= TOL_GL, (name, K, peak_err(y, ref))
+        sc = orc.spectral_convergence(y.astype(np.float64), d["mag"].astype(np.float64), N, H)
+        sc_ref = orc.spectral_convergence(ref, d["mag"].astype(np.float64), N, H)
+        assert abs(sc - sc_ref) <= 1e-3, (name, K, sc, sc_ref)
+        assert np.all(y[-H:] == 0.0)
+    # x0 must not have been modified by the out-of-place calls
+    assert np.array_equal(x0[0].cpu().numpy(), d["x0"].astype(np.float32))
+    p.close()
+
+
+def test_griffin_lim_public_api_uses_numpy_global_rng(golden):
+    """np.random.seed(s) + reference signature reproduces the reference output
+    (audio_utilities.py:176 draws x0 from the global legacy RNG)."""
+    d = golden("gl_smooth_2048_256")
+    np.random.seed(int(d["seed"]))
+    y = au.reconstruct_signal_griffin_lim(d["mag"], 2048, 256, 60)
+    assert y.dtype == np.float64 and y.shape == d["y60"].shape
+    assert peak_err(y, d["y60"]) <= TOL_GL
+    y2 = au.reconstruct_signal_griffin_lim(d["mag"], 2048, 256, 5, x_init=d["x0"])
+    assert peak_err(y2, d["y5"]) <= TOL_GL
+    # zero iterations returns the start signal
+    y0 = au.reconstruct_signal_griffin_lim(d["mag"], 2048, 256, 0, x_init=d["x0"])
+    assert np.array_equal(y0, d["x0"].astype(np.float32).astype(np.float64))
+    with pytest.raises(ValueError):
+        au.reconstruct_signal_griffin_lim(d["mag"][:, :-1], 2048, 256, 1)
+
+
+@pytest.mark.parametrize("path", PATHS)
+def test_batch_equals_single_bitwise(golden, path):
+    """Utterances are independent: a batch gives bit-identical rows to one-at-a-time
+    runs (the basis of per-utterance multi-GPU sharding)."""
+    N, H, T, B = 2048, 256, 45, 5
+    rng = np.random.default_rng(9)
+    mag = torch.from_numpy(np.abs(rng.standard_normal((B, T, N // 2 + 1))).astype(np.float32)).cuda()
+    x0 = torch.from_numpy(rng.standard_normal((B, T * H + N)).astype(np.float32)).cuda()
+    p = _plan(N, H, T, B, path)
+    yb = p.run(mag, x0, 7)
+    for i in range(B):
+        yi = p.run(mag[i:i + 1].contiguous(), x0[i:i + 1].contiguous(), 7)
+        assert torch.equal(yi[0], yb[i])
+    # and run-to-run determinism
+    assert torch.equal(p.run(mag, x0, 7), yb)
+    p.close()
+
+
+def test_fused_matches_generic_ragged_lengths():
+    """Frame counts that are not multiples of any internal run length, both geometries."""
+    rng = np.random.default_rng(21)
+    for N, H, Ts in [(2048, 256, [1, 2, 7, 8, 9, 31, 33, 100]), (1024, 275, [1, 3, 4, 5, 37, 64])]:
+        for T in Ts:
+            mag = torch.from_numpy(np.abs(rng.standard_normal((2, T, N // 2 + 1))).astype(np.float32)).cuda()
+            x0 = torch.from_numpy(rng.standard_normal((2, T * H + N)).astype(np.float32)).cuda()
+            pa, pg = _plan(N, H, T, 2, 0), _plan(N, H, T, 2, 1)
+            ya, yg = pa.run(mag, x0, 3).cpu().numpy(), pg.run(mag, x0, 3).cpu().numpy()
+            ref = np.stack([orc.griffin_lim_vec(mag[i].cpu().numpy().astype(np.float64), N, H, 3,
+                                                x0[i].cpu().numpy().astype(np.float64)) for i in range(2)])
+            assert peak_err(ya, ref) <= TOL_GL and peak_err(yg, ref) <= TOL_GL, (N, H, T)
+            pa.close(); pg.close()
+
+
+# ---- a-2 -------------------------------------------------------------------------------
+def test_mel_to_mag_golden(golden):
+    d = golden("mel_inv_2048")
+    p = Plan(2048, 256, d["mel"].shape[1], 1)
+    fb = torch.from_numpy(np.ascontiguousarray(d["basis"].T)).cuda()       # (80, F)
+    mel = torch.from_numpy(d["mel"]).cuda()[None]
+    mag = p.mel_to_mag(fb, mel)[0].cpu().numpy()
+    assert mag.shape == d["mag"].shape
+    assert np.allclose(mag, d["mag"], rtol=2e-6, atol=1e-6)
+    # MFMA fp32 == k-ordered fp32 fma chain: compare with a float64 dot as well
+    ref64 = np.dot(d["basis"].astype(np.float64), d["mel"].astype(np.float64)).T
+    assert peak_err(mag, ref64) <= 1e-6
+    p.close()
+
+
+def test_mel_to_mag_ragged_shapes():
+    rng = np.random.default_rng(3)
+    for N, n_mels, T, B in [(1024, 80, 1, 1), (1024, 80, 33, 2), (2048, 80, 129, 3), (64, 7, 5, 2), (2048, 81, 31, 1)]:
+        F = N // 2 + 1
+        fb = np.abs(rng.standard_normal((n_mels, F))).astype(np.float32)
+        mel = np.abs(rng.standard_normal((B, n_mels, T))).astype(np.float32)
+        p = Plan(N, 16, T, B)
+        got = p.mel_to_mag(torch.from_numpy(fb).cuda(), torch.from_numpy(mel).cuda()).cpu().numpy()
+        ref = np.einsum("mf,bmt->btf", fb.astype(np.float64), mel.astype(np.float64))
+        assert peak_err(got, ref) <= 1e-6, (N, n_mels, T, B)
+        p.close()
+
+
+def test_save_mel_to_wav_cfg1(golden, tmp_path, monkeypatch):
+    """BASELINE config 1: one ~8 s utterance, params.py defaults (n_fft 1024, hop 275),
+    60 iterations, np.random.seed(42) -> reference waveform within 1e-3 of peak."""
+    d = golden("save_mel_to_wav_cfg1")
+    monkeypatch.setattr(griffin_lim.params, "audio_out_path", str(tmp_path))
+    np.random.seed(int(d["seed"]))
+    lin = griffin_lim.save_mel_to_wav(d["mel"].T.copy().T, "cfg1", iterations=int(d["iters"]))  # non-contiguous view
+    assert lin.shape == (513, 641)
+    fb = orc.mel_filterbank_slaney(22050, 1024, 80, 125, 7600)
+    assert np.allclose(lin, np.dot(fb.T, d["mel"]), rtol=1e-5, atol=1e-6)
+    import wave
+    w = wave.open(str(tmp_path / "cfg1.wav"))
+    assert (w.getnchannels(), w.getsampwidth(), w.getframerate()) == (1, 2, 22050)
+    pcm = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2")
+    assert pcm.shape == d["pcm"].shape
+    # waveform parity: 1e-3 of peak -> <= 33 LSB of the full-scale PCM (+1 for rounding)
+    assert np.max(np.abs(pcm.astype(int) - d["pcm"].astype(int))) <= 34
+    # and directly on the float waveform
+    np.random.seed(int(d["seed"]))
+    x, _ = griffin_lim.mel_to_audio(d["mel"], iterations=int(d["iters"]), normalize=None)
+    assert peak_err(x[0].cpu().numpy(), d["y"]) <= TOL_GL
+
+
+def test_peak_normalise_modes():
+    p = Plan(64, 16, 4, 3)
+    x = torch.tensor([[0.5, -0.25, 0.1, 0.0], [2.0, -4.0, 1.0, 0.5], [0.0, 0.0, 0.0, 0.0]], device="cuda")
+    a = x.clone()
+    peaks = p.peak_normalise(a, mode=0)          # griffin_lim.py:27-29: only when peak > 1
+    assert torch.equal(peaks.cpu(), torch.tensor([0.5, 4.0, 0.0]))
+    assert torch.equal(a[0], x[0]) and torch.equal(a[1], x[1] / 4.0) and torch.equal(a[2], x[2])
+    b = x.clone()
+    p.peak_normalise(b, mode=1)
+    assert torch.equal(b[0], x[0] / 0.5) and torch.equal(b[1], x[1] / 4.0) and torch.equal(b[2], x[2])
+    p.close()
+
+
+def test_device_randn_statistics():
+    p = Plan(64, 16, 4, 1)
+    z = p.randn((1, 1 << 20), seed=42)
+    z2 = p.randn((1, 1 << 20), seed=42)
+    z3 = p.randn((1, 1 << 20), seed=43)
+    assert torch.equal(z, z2) and not torch.equal(z, z3)
+    assert abs(float(z.mean())) < 5e-3 and abs(float(z.std()) - 1.0) < 5e-3
+    assert float(z.abs().max()) < 7.0
+    p.close()
+
+
+# ---- BASELINE config 2 geometry at full size -----------------------------------------------
+def test_config2_full_size_properties_and_parity():
+    """n_fft 2048, hop 256, T=861 (10.09 s), 60 iterations.  One utterance is checked
+    against the float64 oracle; the whole batch through size-independent properties:
+    batch rows identical to single runs, zero tail, spectral convergence improves."""
+    N, H, T, K = 2048, 256, 861, 60
+    F = N // 2 + 1
+    B = 4
+    rng = np.random.default_rng(1234)
+    u = rng.normal(-2.0, 1.5, size=(B, 80, T)).astype(np.float32)
+    mel = torch.from_numpy(np.exp(u)).cuda()
+    fb = torch.from_numpy(filters.mel(22050, N, 80, 125, 7600)).cuda()
+    p = get_plan(N, H, T, B)
+    mag = p.mel_to_mag(fb, mel)
+    x0 = torch.from_numpy(np.random.default_rng(42).standard_normal((B, T * H + N)).astype(np.float32)).cuda()
+    y = p.run(mag, x0, K)
+    y1 = p.run(mag[1:2].contiguous(), x0[1:2].contiguous(), K)
+    assert torch.equal(y1[0], y[1])
+    assert torch.all(y[:, -H:] == 0)
+    mag0 = mag[0].cpu().numpy().astype(np.float64)
+    ref = orc.griffin_lim_vec(mag0, N, H, K, x0[0].cpu().numpy().astype(np.float64))
+    got = y[0].cpu().numpy().astype(np.float64)
+    assert peak_err(got, ref) <= TOL_GL
+    sc, sc_ref = orc.spectral_convergence(got, mag0, N, H), orc.spectral_convergence(ref, mag0, N, H)
+    assert abs(sc - sc_ref) <= 1e-3
+    sc0 = orc.spectral_convergence(x0[0].cpu().numpy().astype(np.float64), mag0, N, H)
+    assert sc < sc0

@@ -54,7 +54,7 @@ def smooth_mag(rng, T, F):
     k_f /= k_f.sum()
     u = np.apply_along_axis(lambda r: np.convolve(r, k_f, mode="valid"), 1, u)
     u = np.apply_along_axis(lambda c: np.convolve(c, k_t, mode="valid"), 0, u)
-    return np.exp(u[:T, :F] * 2.0).astype(np.float32)
+    return np.ascontiguousarray(np.exp(u[:T, :F] * 2.0).astype(np.float32))
 
 
 def save(name, **arrs):

@@ -53,6 +53,9 @@ def lib():
             f"{LIB_PATH} not found: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()' or make -C tacotron2_amd/csrc). "
             "There is no CPU fallback for the Griffin-Lim path.")
+    # PyTorch-ROCm ships its own libamdhip64; load it first so that this library binds
+    # to the SAME HIP runtime (streams and device pointers are shared with torch).
+    import torch  # noqa: F401
     handle = ctypes.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(handle, name)  # AttributeError if the export is missing

@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""Lane-level numpy model of the fused wave-per-frame kernel's data movement
+(gl_fast.hip), used to validate the index maps on the CPU before the HIP code
+runs on a GPU -- TEST INFRASTRUCTURE ONLY (never imported by the product).
+
+Model: one 64-lane wave per frame; M = N/2 complex points, R = M/64 per lane.
+  N=2048: M=1024 = 16 (pass 1, over n2) x 8 (pass 2, over b) x 8 (pass 3, over a)
+     n = a + 8 b + 64 n2          k = k2 + 16 d + 128 c
+Each "lane" below is a row of a [64][R] complex array.
+"""
+import numpy as np
+
+
+def W(n, k):
+    return np.exp(-2j * np.pi * k / n)
+
+
+def forward_2048(z):
+    """z: [1024] complex (packed even/odd windowed frame) -> ZA[64][8], ZB[64][8]
+    with ZA[l][c] = Z[l + 128 c], ZB[l][c] = Z[(128-l) + 128 c] (lane 0: Z[64 + 128 c])."""
+    M = 1024
+    # pass 1: lane n1, regs n2
+    reg = np.zeros((64, 16), complex)
+    for l in range(64):
+        for j in range(16):
+            reg[l, j] = z[l + 64 * j]
+    y1 = np.zeros((64, 16), complex)
+    for l in range(64):
+        for k2 in range(16):
+            y1[l, k2] = sum(reg[l, n2] * W(16, n2 * k2) for n2 in range(16)) * W(1024, l * k2)
+    # exchange 1: lds1[k2*72 + n1]
+    lds = np.zeros(16 * 72, complex)
+    for l in range(64):
+        for k2 in range(16):
+            lds[k2 * 72 + l] = y1[l, k2]
+    # pass 2: lane l2 = a + 8 g; butterflies k2 = g + 8 h; regs [h][b]
+    y2 = np.zeros((64, 2, 8), complex)
+    for l in range(64):
+        a, g = l & 7, l >> 3
+        for h in range(2):
+            v = [lds[(g + 8 * h) * 72 + a + 8 * b] for b in range(8)]
+            for d in range(8):
+                y2[l, h, d] = sum(v[b] * W(8, b * d) for b in range(8)) * W(64, a * d)
+    # exchange 2: lds2[a*130 + 16 d + k2]
+    lds = np.zeros(8 * 130, complex)
+    for l in range(64):
+        a, g = l & 7, l >> 3
+        for h in range(2):
+            for d in range(8):
+                lds[a * 130 + 16 * d + g + 8 * h] = y2[l, h, d]
+    # pass 3: lane l3: butterfly A k_lo = l3, B k_lo = 128 - l3 (lane 0: 64)
+    ZA = np.zeros((64, 8), complex)
+    ZB = np.zeros((64, 8), complex)
+    for l in range(64):
+        for which, klo in ((0, l), (1, 128 - l if l else 64)):
+            v = [lds[a * 130 + klo] for a in range(8)]
+            out = [sum(v[a] * W(8, a * c) for a in range(8)) for c in range(8)]
+            (ZA if which == 0 else ZB)[l] = out
+    return ZA, ZB
+
+
+def inverse_2048(ZA, ZB):
+    """Exact reverse flow; returns z[1024] = IFFT (unnormalised: multiply by 1/1024 outside)."""
+    lds = np.zeros(8 * 130, complex)
+    for l in range(64):
+        for which, klo in ((0, l), (1, 128 - l if l else 64)):
+            src = ZA[l] if which == 0 else ZB[l]
+            for a in range(8):
+                lds[a * 130 + klo] = sum(src[c] * np.conj(W(8, a * c)) for c in range(8))
+    y2 = np.zeros((64, 2, 8), complex)
+    for l in range(64):
+        a, g = l & 7, l >> 3
+        for h in range(2):
+            u = [lds[a * 130 + 16 * d + g + 8 * h] * np.conj(W(64, a * d)) for d in range(8)]
+            for b in range(8):
+                y2[l, h, b] = sum(u[d] * np.conj(W(8, b * d)) for d in range(8))
+    lds = np.zeros(16 * 72, complex)
+    for l in range(64):
+        a, g = l & 7, l >> 3
+        for h in range(2):
+            for b in range(8):
+                lds[(g + 8 * h) * 72 + a + 8 * b] = y2[l, h, b]
+    z = np.zeros(1024, complex)
+    for l in range(64):
+        v = [lds[k2 * 72 + l] * np.conj(W(1024, l * k2)) for k2 in range(16)]
+        for n2 in range(16):
+            z[l + 64 * n2] = sum(v[k2] * np.conj(W(16, n2 * k2)) for k2 in range(16))
+    return z
+
+
+def pair_fwd(zk, zm, w):
+    A = 0.5 * (zk + np.conj(zm))
+    Zo = -0.5j * (zk - np.conj(zm))
+    Bv = w * Zo
+    return A + Bv, np.conj(A - Bv)
+
+
+def pair_inv(Xk, Xmk, w):
+    A = 0.5 * (Xk + np.conj(Xmk))
+    Bv = 0.5 * (Xk - np.conj(Xmk))
+    Zo = np.conj(w) * Bv
+    return A + 1j * Zo, np.conj(A) + 1j * np.conj(Zo)
+
+
+def project(X, m):
+    r = abs(X)
+    return X * (m / r) if r > 0 else complex(m, 0.0)
+
+
+def middle_2048(ZA, ZB, mag):
+    """rfft post-process + magnitude projection + irfft pre-process, all lane-local.
+    mag: [1025].  Returns Z'A, Z'B and the rfft spectrum X[1025] (for checking)."""
+    M = 1024
+    X = np.zeros(M + 1, complex)
+    ZA2 = np.zeros_like(ZA)
+    ZB2 = np.zeros_like(ZB)
+    for l in range(64):
+        if l:
+            P = [(0, c) for c in range(8)]               # (which, idx)
+            Q = [(1, 7 - c) for c in range(8)]
+            kP = [l + 128 * c for c in range(8)]
+            extra = None
+        else:
+            P = [(0, 0), (0, 1), (0, 2), (0, 3), (1, 0), (1, 1), (1, 2), (1, 3)]
+            Q = [(0, 0), (0, 7), (0, 6), (0, 5), (1, 7), (1, 6), (1, 5), (1, 4)]
+            kP = [0, 128, 256, 384, 64, 192, 320, 448]
+            extra = ((0, 4), (0, 4), 512)
+        units = list(zip(P, Q, kP)) + ([extra] if extra else [])
+        for (pw, pi), (qw, qi), k in units:
+            src = (ZA, ZB)
+            zk, zm = src[pw][l, pi], src[qw][l, qi]
+            w = W(2048, k)
+            Xk, Xmk = pair_fwd(zk, zm, w)
+            X[k], X[M - k] = Xk, Xmk
+            Xk, Xmk = project(Xk, mag[k]), project(Xmk, mag[M - k])
+            z1, z2 = pair_inv(Xk, Xmk, w)
+            dst = (ZA2, ZB2)
+            dst[qw][l, qi] = z2
+            dst[pw][l, pi] = z1       # P written last: for self pairs z1 == z2
+    return ZA2, ZB2, X
+
+
+def main():
+    rng = np.random.default_rng(0)
+    N, M = 2048, 1024
+    win = np.hanning(N)
+    x = rng.standard_normal(N)
+    xw = win * x
+    z = xw[0::2] + 1j * xw[1::2]
+    ZA, ZB = forward_2048(z)
+    Zref = np.fft.fft(z)
+    for l in range(64):
+        for c in range(8):
+            assert abs(ZA[l, c] - Zref[l + 128 * c]) < 1e-9
+            assert abs(ZB[l, c] - Zref[(128 - l if l else 64) + 128 * c]) < 1e-9
+    print("forward map ok")
+    zr = inverse_2048(ZA, ZB) / M
+    assert np.max(np.abs(zr - z)) < 1e-12
+    print("inverse map ok")
+    mag = np.abs(rng.standard_normal(M + 1))
+    ZA2, ZB2, X = middle_2048(ZA, ZB, mag)
+    Xref = np.fft.rfft(xw)
+    assert np.max(np.abs(X - Xref)) < 1e-9, np.max(np.abs(X - Xref))
+    print("rfft post-process ok")
+    z2 = inverse_2048(ZA2, ZB2) / M
+    y = np.empty(N)
+    y[0::2], y[1::2] = z2.real, z2.imag
+    yref = np.fft.irfft(mag * np.exp(1j * np.angle(Xref)))
+    assert np.max(np.abs(y - yref)) < 1e-9, np.max(np.abs(y - yref))
+    assert np.max(np.abs(z2.imag - yref[1::2])) < 1e-9
+    print("projection + irfft ok")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,17 +1,590 @@
-// Fused wave-per-frame Griffin-Lim kernels (placeholder until the register-FFT
-// kernels land; gl_fast_supported() gates every call).
+// Fused wave-per-frame Griffin-Lim kernels for gfx950 (MI355X), n_fft = 2048.
+//
+// One 64-lane wavefront owns a run of G consecutive frames of one utterance and
+// keeps the whole per-frame pipeline on chip:
+//
+//   x ring (LDS) -> window -> 1024-point complex FFT in registers (16 points per
+//   lane: radix-16, radix-8, radix-8 with two LDS transposes) -> real-FFT
+//   post-process + magnitude projection + inverse pre-process, lane-local ->
+//   inverse FFT (mirror image) -> window -> overlap-add into an LDS ring ->
+//   each output sample written to HBM exactly once.
+//
+// The index decomposition n = a + 8b + 64 n2, k = k2 + 16 d + 128 c and the lane
+// assignment of the last pass (lane l owns the radix-8 butterflies k_lo = l and
+// k_lo = 128 - l) put every mirror pair (k, 1024-k) of the real-FFT split in ONE
+// lane, so the projection needs no cross-lane traffic.  The maps are modelled and
+// checked on the CPU in oracle/sim_fast2048.py.
+//
+// A wave is its own workgroup: LDS operations of one wave execute in order, so the
+// transposes need no barriers.  Runs of one utterance overlap by N-H samples; each
+// run writes the partial sums of its trailing N-H samples to a side buffer ("tail")
+// that the consumer (the next iteration's ring fill, or the final fold kernel) adds
+// back -- plain stores, no atomics, fixed summation order (frame order, like the
+// reference's `x[i:i+N] += ...` loop), so results are bit-reproducible and
+// independent of batch composition.
+//
+// Replaces audio_utilities.py:91-92 (frame*window, rfft), :181-183 (projection),
+// :112-113 (irfft, window, overlap-add) per iteration of :178-187.
+#include <math.h>
+
+#include <vector>
+
 #include "gl_internal.h"
 
-bool gl_fast_supported(const gl_plan* p) {
-    (void)p;
-    return false;
+namespace {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+constexpr int kN = 2048;           // n_fft
+constexpr int kM = 1024;           // complex points
+constexpr int kRing = kN;          // ring length (floats), power of two
+constexpr int kEx1Stride = 72;     // exchange-1 row stride (complex), 64 + 8 pad
+constexpr int kEx2Stride = 130;    // exchange-2 row stride (complex), 128 + 2 pad
+constexpr int kScratch = 16 * kEx1Stride;   // complex elements (>= 8*kEx2Stride)
+static_assert(kScratch >= 8 * kEx2Stride, "scratch too small");
+
+// per-lane constant table, entry-major: tab[e*64 + lane]
+constexpr int kTabWin = 0;         // 32 floats: w[2(l+64j)], w[2(l+64j)+1]
+constexpr int kTabTw1 = 32;        // 15 complex: W1024^(l*k2), k2 = 1..15
+constexpr int kTabTw2 = 62;        // 7 complex:  W64^(a*d),   d = 1..7, a = l&7
+constexpr int kTabTwp = 76;        // 9 complex:  W2048^(kP[u]), u = 0..8
+constexpr int kTabEntries = 94;
+
+enum { MODE_GL = 0, MODE_STFT = 1, MODE_ISTFT = 2 };
+
+// ---- complex helpers on v2f --------------------------------------------------------------
+__device__ __forceinline__ v2f cmul(v2f a, v2f w) {
+    v2f r;
+    r.x = a.x * w.x - a.y * w.y;
+    r.y = a.x * w.y + a.y * w.x;
+    return r;
 }
-int gl_fast_stft(gl_plan*, const float*, long long, float*, int, int, hipStream_t) {
-    return gl_set_error(GL_ERR_UNSUPPORTED, "fused path not available for this geometry");
+__device__ __forceinline__ v2f cmulc(v2f a, v2f w) {  // a * conj(w)
+    v2f r;
+    r.x = a.x * w.x + a.y * w.y;
+    r.y = a.y * w.x - a.x * w.y;
+    return r;
 }
-int gl_fast_istft(gl_plan*, const float*, float*, int, int, hipStream_t) {
-    return gl_set_error(GL_ERR_UNSUPPORTED, "fused path not available for this geometry");
+template <bool INV>
+__device__ __forceinline__ v2f ctw(v2f a, v2f w) { return INV ? cmulc(a, w) : cmul(a, w); }
+__device__ __forceinline__ v2f mul_mi(v2f a) { v2f r; r.x = a.y; r.y = -a.x; return r; }   // -i*a
+__device__ __forceinline__ v2f mul_pi(v2f a) { v2f r; r.x = -a.y; r.y = a.x; return r; }   // +i*a
+__device__ __forceinline__ v2f cconj(v2f a) { v2f r; r.x = a.x; r.y = -a.y; return r; }
+
+template <bool INV>
+__device__ __forceinline__ void dft4(v2f& a0, v2f& a1, v2f& a2, v2f& a3) {
+    v2f s0 = a0 + a2, s1 = a0 - a2, s2 = a1 + a3, s3 = a1 - a3;
+    v2f t = INV ? mul_pi(s3) : mul_mi(s3);
+    a0 = s0 + s2;
+    a2 = s0 - s2;
+    a1 = s1 + t;
+    a3 = s1 - t;
 }
-int gl_fast_run(gl_plan*, const float*, const float*, float*, int, int, int, hipStream_t) {
-    return gl_set_error(GL_ERR_UNSUPPORTED, "fused path not available for this geometry");
+
+// multiply by W8^1 / W8^3 (forward: exp(-i*pi/4), exp(-3i*pi/4); inverse: conjugates)
+template <bool INV>
+__device__ __forceinline__ v2f mul_w8_1(v2f a) {
+    const float h = 0.70710678118654752440f;
+    v2f r;
+    if (!INV) { r.x = (a.x + a.y) * h; r.y = (a.y - a.x) * h; }
+    else      { r.x = (a.x - a.y) * h; r.y = (a.x + a.y) * h; }
+    return r;
+}
+template <bool INV>
+__device__ __forceinline__ v2f mul_w8_3(v2f a) {
+    const float h = 0.70710678118654752440f;
+    v2f r;
+    if (!INV) { r.x = (a.y - a.x) * h; r.y = -(a.x + a.y) * h; }
+    else      { r.x = -(a.x + a.y) * h; r.y = (a.x - a.y) * h; }
+    return r;
+}
+
+// natural-order in-place DFT-8 on v[0..7]
+template <bool INV>
+__device__ __forceinline__ void dft8(v2f* v) {
+    dft4<INV>(v[0], v[2], v[4], v[6]);   // E0..E3 in v0,v2,v4,v6
+    dft4<INV>(v[1], v[3], v[5], v[7]);   // O0..O3 in v1,v3,v5,v7
+    v2f o1 = mul_w8_1<INV>(v[3]);
+    v2f o2 = INV ? mul_pi(v[5]) : mul_mi(v[5]);
+    v2f o3 = mul_w8_3<INV>(v[7]);
+    v2f e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1];
+    v[0] = e0 + o0; v[4] = e0 - o0;
+    v[1] = e1 + o1; v[5] = e1 - o1;
+    v[2] = e2 + o2; v[6] = e2 - o2;
+    v[3] = e3 + o3; v[7] = e3 - o3;
+}
+
+// natural-order in-place DFT-16 on v[0..15]
+template <bool INV>
+__device__ __forceinline__ void dft16(v2f* v) {
+    const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f;  // cos, sin(pi/8)
+    // step 1: for r = 0..3, DFT4 over m of x[r + 4m] -> E_r[q] kept in v[r + 4q]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dft4<INV>(v[r], v[r + 4], v[r + 8], v[r + 12]);
+    // step 2: twiddle E_r[q] *= W16^(r*q)
+    const v2f w1 = {c1, -s1}, w3 = {s1, -c1};     // W16^1, W16^3 (forward)
+    v[5] = ctw<INV>(v[5], w1);                    // r=1,q=1
+    v[9] = mul_w8_1<INV>(v[9]);                   // r=1,q=2 : W16^2
+    v[13] = ctw<INV>(v[13], w3);                  // r=1,q=3
+    v[6] = mul_w8_1<INV>(v[6]);                   // r=2,q=1 : W16^2
+    v[10] = INV ? mul_pi(v[10]) : mul_mi(v[10]);  // r=2,q=2 : W16^4
+    v[14] = mul_w8_3<INV>(v[14]);                 // r=2,q=3 : W16^6
+    v[7] = ctw<INV>(v[7], w3);                    // r=3,q=1
+    v[11] = mul_w8_3<INV>(v[11]);                 // r=3,q=2 : W16^6
+    {                                             // r=3,q=3 : W16^9 = -W16^1
+        v2f t = ctw<INV>(v[15], w1);
+        v[15] = -t;
+    }
+    // step 3: for q = 0..3, DFT4 over r of v[r + 4q] -> X[q + 4p] ; then reorder
+    v2f out[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        v2f a0 = v[4 * q], a1 = v[4 * q + 1], a2 = v[4 * q + 2], a3 = v[4 * q + 3];
+        dft4<INV>(a0, a1, a2, a3);
+        out[q] = a0; out[q + 4] = a1; out[q + 8] = a2; out[q + 12] = a3;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = out[i];
+}
+
+// rfft split for the mirror pair (k, M-k): Z[k], Z[M-k] -> X[k], X[M-k]
+__device__ __forceinline__ void pair_fwd(v2f zk, v2f zm, v2f w, v2f& Xk, v2f& Xmk) {
+    v2f A, Zo;
+    A.x = 0.5f * (zk.x + zm.x);  A.y = 0.5f * (zk.y - zm.y);
+    Zo.x = 0.5f * (zk.y + zm.y); Zo.y = -0.5f * (zk.x - zm.x);
+    v2f Bv = cmul(w, Zo);
+    Xk = A + Bv;
+    Xmk = cconj(A - Bv);
+}
+// inverse: X[k], X[M-k] -> Z[k], Z[M-k] of the packed inverse transform
+__device__ __forceinline__ void pair_inv(v2f Xk, v2f Xmk, v2f w, v2f& zk, v2f& zm) {
+    v2f A, Bv;
+    A.x = 0.5f * (Xk.x + Xmk.x);  A.y = 0.5f * (Xk.y - Xmk.y);
+    Bv.x = 0.5f * (Xk.x - Xmk.x); Bv.y = 0.5f * (Xk.y + Xmk.y);
+    v2f Zo = cmulc(Bv, w);
+    zk.x = A.x - Zo.y;  zk.y = A.y + Zo.x;
+    zm.x = A.x + Zo.y;  zm.y = Zo.x - A.y;
+}
+__device__ __forceinline__ v2f project(v2f X, float m) {
+    float2 r = gl_project(make_float2(X.x, X.y), m);
+    v2f o = {r.x, r.y};
+    return o;
+}
+
+struct FastArgs {
+    const float* x_in;       // [B][L]   (GL, STFT)
+    long long x_stride;      // samples between utterances of x_in
+    const float* tail_in;    // [B][nruns][N-H] or null
+    int g_in;                // frames per run used by the producer of tail_in
+    int nruns_in;
+    const float* mag;        // [B][T][F]          (GL)
+    const float2* S_in;      // [B][T][F] complex  (ISTFT)
+    float2* S_out;           // [B][T][F] complex  (STFT)
+    float* x_out;            // [B][L]             (GL, ISTFT)
+    float* tail_out;         // [B][nruns][N-H]
+    const float* tab;        // per-lane constants
+    int H, T, G, nruns;
+    long long L;
+};
+
+// x sample s of utterance row `xr`, with the producer's run tails folded in
+__device__ __forceinline__ float fetch_x(const float* __restrict__ xr, const float* __restrict__ tr, long long s,
+                                         int g_in_h, int nruns_in, int ovl) {
+    float v = xr[s];
+    if (tr != nullptr) {
+        int k = (int)(s / g_in_h);
+        if (k > nruns_in - 1) k = nruns_in - 1;
+        int i = (int)(s - (long long)k * g_in_h);
+        if (k >= 1 && i < ovl) v += tr[(long long)(k - 1) * ovl + i];
+    }
+    return v;
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(64) k_fast2048(FastArgs p) {
+    __shared__ __attribute__((aligned(16))) float xring[kRing];
+    __shared__ __attribute__((aligned(16))) float acc[kRing];
+    __shared__ __attribute__((aligned(16))) v2f ex[kScratch];
+
+    const int l = threadIdx.x;
+    const int b = blockIdx.y;
+    const int run = blockIdx.x;
+    const int H = p.H, T = p.T;
+    const int f0 = run * p.G;
+    const int f1 = min(f0 + p.G, T);
+    const int ovl = kN - H;                       // samples shared by neighbouring runs
+    const int a3 = l & 7, g3 = l >> 3;            // pass-2 lane coordinates
+    const int kloB = l ? 128 - l : 64;            // pass-3 second butterfly
+
+    // ---- per-lane constants ----------------------------------------------------------
+    const float* tab = p.tab + l;
+    float win[32];
+    v2f tw1[16], tw2[8], twp[9];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) win[i] = tab[(kTabWin + i) * 64];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) { tw1[i].x = tab[(kTabTw1 + 2 * (i - 1)) * 64]; tw1[i].y = tab[(kTabTw1 + 2 * (i - 1) + 1) * 64]; }
+#pragma unroll
+    for (int i = 1; i < 8; ++i) { tw2[i].x = tab[(kTabTw2 + 2 * (i - 1)) * 64]; tw2[i].y = tab[(kTabTw2 + 2 * (i - 1) + 1) * 64]; }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { twp[i].x = tab[(kTabTwp + 2 * i) * 64]; twp[i].y = tab[(kTabTwp + 2 * i + 1) * 64]; }
+    int kP[9];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) kP[c] = l ? (l + 128 * c) : (c < 4 ? 128 * c : 64 + 128 * (c - 4));
+    kP[8] = 512;
+
+    const float* xr = nullptr;
+    const float* tr = nullptr;
+    const int g_in_h = p.g_in * H;
+    if (MODE != MODE_ISTFT) {
+        xr = p.x_in + (long long)b * p.x_stride;
+        if (p.tail_in) tr = p.tail_in + (long long)b * p.nruns_in * ovl;
+    }
+
+    // ---- ring initialisation ----------------------------------------------------------------
+    if (MODE != MODE_STFT) {
+#pragma unroll
+        for (int i = 0; i < kRing / 64; ++i) acc[l + 64 * i] = 0.0f;
+    }
+    if (MODE != MODE_ISTFT) {
+        const long long s0 = (long long)f0 * H;
+        for (int i = l; i < ovl; i += 64) xring[(int)((s0 + i) & (kRing - 1))] = fetch_x(xr, tr, s0 + i, g_in_h, p.nruns_in, ovl);
+    }
+
+    for (int n = f0; n < f1; ++n) {
+        const long long sn = (long long)n * H;      // first sample of frame n
+        v2f z[16];
+        float m_lo[9], m_hi[9];
+
+        if (MODE == MODE_GL) {
+            const float* mrow = p.mag + ((long long)b * T + n) * (kM + 1);
+#pragma unroll
+            for (int u = 0; u < 9; ++u) { m_lo[u] = mrow[kP[u]]; m_hi[u] = mrow[kM - kP[u]]; }
+        }
+
+        if (MODE != MODE_ISTFT) {
+            // append the H new samples [sn + N - H, sn + N) and read the frame
+            for (int i = l; i < H; i += 64) {
+                long long s = sn + ovl + i;
+                xring[(int)(s & (kRing - 1))] = fetch_x(xr, tr, s, g_in_h, p.nruns_in, ovl);
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int base = (int)(sn & (kRing - 1));
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                int q = base + 2 * (l + 64 * j);
+                z[j].x = xring[q & (kRing - 1)] * win[2 * j];
+                z[j].y = xring[(q + 1) & (kRing - 1)] * win[2 * j + 1];
+            }
+            // ---- forward pass 1: DFT-16 over n2, twiddle W1024^(n1*k2) -------------------------
+            dft16<false>(z);
+#pragma unroll
+            for (int k2 = 1; k2 < 16; ++k2) z[k2] = cmul(z[k2], tw1[k2]);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k2 = 0; k2 < 16; ++k2) ex[k2 * kEx1Stride + l] = z[k2];
+            __builtin_amdgcn_wave_barrier();
+            // ---- pass 2: lane (a, g): butterflies k2 = g + 8h over b, twiddle W64^(a*d) -----------
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int bb = 0; bb < 8; ++bb) z[8 * h + bb] = ex[(g3 + 8 * h) * kEx1Stride + a3 + 8 * bb];
+            dft8<false>(z);
+            dft8<false>(z + 8);
+#pragma unroll
+            for (int d = 1; d < 8; ++d) { z[d] = cmul(z[d], tw2[d]); z[8 + d] = cmul(z[8 + d], tw2[d]); }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int d = 0; d < 8; ++d) ex[a3 * kEx2Stride + 16 * d + g3 + 8 * h] = z[8 * h + d];
+            __builtin_amdgcn_wave_barrier();
+            // ---- pass 3: butterflies k_lo = l (A) and 128-l (B) over a ------------------------------
+#pragma unroll
+            for (int a = 0; a < 8; ++a) { z[a] = ex[a * kEx2Stride + l]; z[8 + a] = ex[a * kEx2Stride + kloB]; }
+            dft8<false>(z);
+            dft8<false>(z + 8);
+        }
+
+        // ---- middle: 9 mirror-pair units, lane-local ---------------------------------------------------
+        // lanes >= 1: P[c] = A[c], Q[c] = B[7-c]; lane 0: see oracle/sim_fast2048.py
+        {
+            const bool l0 = (l == 0);
+            v2f P[9], Q[9];
+            if (MODE != MODE_ISTFT) {
+                P[0] = z[0];
+                Q[0] = l0 ? z[0] : z[15];
+#pragma unroll
+                for (int c = 1; c < 4; ++c) { P[c] = z[c]; Q[c] = l0 ? z[8 - c] : z[15 - c]; }
+#pragma unroll
+                for (int c = 4; c < 8; ++c) { P[c] = l0 ? z[8 + c - 4] : z[c]; Q[c] = l0 ? z[8 + 11 - c] : z[15 - c]; }
+                P[8] = z[4];
+                Q[8] = z[4];
+            }
+            v2f Pn[9], Qn[9];
+#pragma unroll
+            for (int u = 0; u < 9; ++u) {
+                v2f Xk, Xmk;
+                if (MODE != MODE_ISTFT) {
+                    pair_fwd(P[u], Q[u], twp[u], Xk, Xmk);
+                } else {
+                    const float2* srow = p.S_in + ((long long)b * T + n) * (kM + 1);
+                    float2 s1 = srow[kP[u]], s2 = srow[kM - kP[u]];
+                    Xk.x = s1.x; Xk.y = s1.y; Xmk.x = s2.x; Xmk.y = s2.y;
+                    if (u == 0 && l0) { Xk.y = 0.0f; Xmk.y = 0.0f; }   // irfft ignores imag(DC), imag(Nyquist)
+                }
+                if (MODE == MODE_STFT) {
+                    float2* orow = p.S_out + ((long long)b * T + n) * (kM + 1);
+                    if (u < 8 || l0) {
+                        orow[kP[u]] = make_float2(Xk.x, Xk.y);
+                        orow[kM - kP[u]] = make_float2(Xmk.x, Xmk.y);
+                    }
+                } else {
+                    if (MODE == MODE_GL) { Xk = project(Xk, m_lo[u]); Xmk = project(Xmk, m_hi[u]); }
+                    pair_inv(Xk, Xmk, twp[u], Pn[u], Qn[u]);
+                }
+            }
+            if (MODE == MODE_STFT) continue;
+            // scatter back to the A/B butterfly registers
+            z[0] = Pn[0];
+#pragma unroll
+            for (int c = 1; c < 4; ++c) z[c] = Pn[c];
+            z[4] = l0 ? Pn[8] : Pn[4];
+#pragma unroll
+            for (int c = 5; c < 8; ++c) z[c] = l0 ? Qn[8 - c] : Pn[c];
+            // B[i], i = 0..7
+#pragma unroll
+            for (int i = 0; i < 4; ++i) z[8 + i] = l0 ? Pn[4 + i] : Qn[7 - i];
+#pragma unroll
+            for (int i = 4; i < 8; ++i) z[8 + i] = l0 ? Qn[11 - i] : Qn[7 - i];
+        }
+
+        // ---- inverse pass 3': inverse DFT-8 over c -> a, back through exchange 2 -------------------------
+        dft8<true>(z);
+        dft8<true>(z + 8);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int a = 0; a < 8; ++a) { ex[a * kEx2Stride + l] = z[a]; ex[a * kEx2Stride + kloB] = z[8 + a]; }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int d = 0; d < 8; ++d) z[8 * h + d] = ex[a3 * kEx2Stride + 16 * d + g3 + 8 * h];
+#pragma unroll
+        for (int d = 1; d < 8; ++d) { z[d] = cmulc(z[d], tw2[d]); z[8 + d] = cmulc(z[8 + d], tw2[d]); }
+        dft8<true>(z);
+        dft8<true>(z + 8);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int bb = 0; bb < 8; ++bb) ex[(g3 + 8 * h) * kEx1Stride + a3 + 8 * bb] = z[8 * h + bb];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) z[k2] = ex[k2 * kEx1Stride + l];
+#pragma unroll
+        for (int k2 = 1; k2 < 16; ++k2) z[k2] = cmulc(z[k2], tw1[k2]);
+        dft16<true>(z);
+
+        // ---- window, 1/M, overlap-add into the acc ring ----------------------------------------------------
+        {
+            const float sc = 1.0f / (float)kM;
+            const int base = (int)(sn & (kRing - 1));
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                int q = base + 2 * (l + 64 * j);
+                int q0 = q & (kRing - 1), q1 = (q + 1) & (kRing - 1);
+                acc[q0] += (z[j].x * sc) * win[2 * j];
+                acc[q1] += (z[j].y * sc) * win[2 * j + 1];
+            }
+            __builtin_amdgcn_wave_barrier();
+            // samples [sn, sn+H) are complete: emit and clear
+            float* orow = p.x_out + (long long)b * p.L;
+            for (int i = l; i < H; i += 64) {
+                int q = (int)((sn + i) & (kRing - 1));
+                orow[sn + i] = acc[q];
+                acc[q] = 0.0f;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+
+    if (MODE != MODE_STFT) {
+        // partial sums of the N-H samples after the run's last frame
+        const long long se = (long long)f1 * H;
+        if (f1 == T) {
+            float* orow = p.x_out + (long long)b * p.L;
+            for (int i = l; i < ovl; i += 64) orow[se + i] = acc[(int)((se + i) & (kRing - 1))];
+            for (int i = l; i < H; i += 64) orow[se + ovl + i] = 0.0f;     // no frame covers the last H samples
+        } else {
+            float* trow = p.tail_out + ((long long)b * p.nruns + run) * ovl;
+            for (int i = l; i < ovl; i += 64) trow[i] = acc[(int)((se + i) & (kRing - 1))];
+        }
+    }
+}
+
+// x_out[s] = x_main[s] + tail of the previous run (final fold after the last iteration)
+__global__ void __launch_bounds__(256) k_fold_tails(const float* __restrict__ x_main, const float* __restrict__ tail,
+                                                    float* __restrict__ x_out, long long L, int g_h, int nruns,
+                                                    int ovl) {
+    const int b = blockIdx.y;
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= L) return;
+    x_out[(long long)b * L + s] =
+        fetch_x(x_main + (long long)b * L, tail + (long long)b * nruns * ovl, s, g_h, nruns, ovl);
+}
+
+int pick_run_length(const gl_plan* p, int B, int T) {
+    const int N = p->n_fft, H = p->hop;
+    int g_min = (N - H + H - 1) / H;            // G*H >= N-H: at most two runs touch a sample
+    if (g_min < 1) g_min = 1;
+    int G = 16;
+    if (G < g_min) G = g_min;
+    if (G > T) G = T;
+    (void)B;
+    return G;
+}
+
+int ensure_table(gl_plan* p) {
+    if (p->d_fast_tab) return 0;
+    const int N = p->n_fft;
+    std::vector<float> tab((size_t)kTabEntries * 64, 0.0f);
+    const double pi = 3.14159265358979323846;
+    auto W = [&](int n, long long k, float* re, float* im) {
+        double a = -2.0 * pi * (double)(k % n) / (double)n;
+        *re = (float)cos(a);
+        *im = (float)sin(a);
+    };
+    for (int l = 0; l < 64; ++l) {
+        for (int j = 0; j < 16; ++j)
+            for (int e = 0; e < 2; ++e) {
+                int n = 2 * (l + 64 * j) + e;
+                tab[(size_t)(kTabWin + 2 * j + e) * 64 + l] = (float)(0.5 - 0.5 * cos(2.0 * pi * n / (double)(N - 1)));
+            }
+        for (int k2 = 1; k2 < 16; ++k2)
+            W(1024, (long long)l * k2, &tab[(size_t)(kTabTw1 + 2 * (k2 - 1)) * 64 + l],
+              &tab[(size_t)(kTabTw1 + 2 * (k2 - 1) + 1) * 64 + l]);
+        for (int d = 1; d < 8; ++d)
+            W(64, (long long)(l & 7) * d, &tab[(size_t)(kTabTw2 + 2 * (d - 1)) * 64 + l],
+              &tab[(size_t)(kTabTw2 + 2 * (d - 1) + 1) * 64 + l]);
+        for (int u = 0; u < 9; ++u) {
+            int k = (u == 8) ? 512 : (l ? l + 128 * u : (u < 4 ? 128 * u : 64 + 128 * (u - 4)));
+            W(2048, k, &tab[(size_t)(kTabTwp + 2 * u) * 64 + l], &tab[(size_t)(kTabTwp + 2 * u + 1) * 64 + l]);
+        }
+    }
+    int rc = gl_plan_alloc(p, (void**)&p->d_fast_tab, tab.size() * sizeof(float));
+    if (rc) return rc;
+    GL_HIP_CHECK(hipMemcpy(p->d_fast_tab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int ensure_buffers(gl_plan* p) {
+    const int N = p->n_fft, H = p->hop;
+    size_t xbytes = (size_t)p->max_B * gl_len(N, H, p->max_T) * sizeof(float);
+    int g_min = (N - H + H - 1) / H;
+    if (g_min < 1) g_min = 1;
+    size_t max_runs = (size_t)(p->max_T + g_min - 1) / g_min;
+    size_t tbytes = (size_t)p->max_B * max_runs * (size_t)(N - H) * sizeof(float);
+    int rc = 0;
+    if (!p->d_xa) rc = gl_plan_alloc(p, (void**)&p->d_xa, xbytes);
+    if (!rc && !p->d_xb) rc = gl_plan_alloc(p, (void**)&p->d_xb, xbytes);
+    if (!rc && !p->d_tail_a) rc = gl_plan_alloc(p, (void**)&p->d_tail_a, tbytes);
+    if (!rc && !p->d_tail_b) rc = gl_plan_alloc(p, (void**)&p->d_tail_b, tbytes);
+    return rc;
+}
+
+template <int MODE>
+int launch(const FastArgs& a, int B, hipStream_t st) {
+    dim3 grid(a.nruns, B);
+    hipLaunchKernelGGL(k_fast2048<MODE>, grid, dim3(64), 0, st, a);
+    GL_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int fold(gl_plan* p, const float* x_main, const float* tail, float* x_out, int B, int T, int G, int nruns,
+         hipStream_t st) {
+    const long long L = gl_len(p->n_fft, p->hop, T);
+    dim3 grid((unsigned)((L + 255) / 256), B);
+    hipLaunchKernelGGL(k_fold_tails, grid, dim3(256), 0, st, x_main, tail, x_out, L, G * p->hop, nruns,
+                       p->n_fft - p->hop);
+    GL_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+bool gl_fast_supported(const gl_plan* p) { return p->n_fft == kN && p->hop <= kN && p->hop >= 1; }
+
+int gl_fast_stft(gl_plan* p, const float* x, long long x_stride, float* S, int B, int T, hipStream_t st) {
+    int rc = ensure_table(p);
+    if (rc) return rc;
+    FastArgs a = {};
+    a.x_in = x;
+    a.x_stride = x_stride;
+    a.S_out = (float2*)S;
+    a.tab = p->d_fast_tab;
+    a.H = p->hop;
+    a.T = T;
+    a.G = pick_run_length(p, B, T);
+    a.nruns = (T + a.G - 1) / a.G;
+    a.L = gl_len(p->n_fft, p->hop, T);
+    return launch<MODE_STFT>(a, B, st);
+}
+
+int gl_fast_istft(gl_plan* p, const float* S, float* y, int B, int T, hipStream_t st) {
+    int rc = ensure_table(p);
+    if (!rc) rc = ensure_buffers(p);
+    if (rc) return rc;
+    FastArgs a = {};
+    a.S_in = (const float2*)S;
+    a.tab = p->d_fast_tab;
+    a.H = p->hop;
+    a.T = T;
+    a.G = pick_run_length(p, B, T);
+    a.nruns = (T + a.G - 1) / a.G;
+    a.L = gl_len(p->n_fft, p->hop, T);
+    a.x_out = (a.nruns > 1) ? p->d_xa : y;
+    a.tail_out = p->d_tail_a;
+    rc = launch<MODE_ISTFT>(a, B, st);
+    if (rc || a.nruns == 1) return rc;
+    return fold(p, p->d_xa, p->d_tail_a, y, B, T, a.G, a.nruns, st);
+}
+
+int gl_fast_run(gl_plan* p, const float* mag, const float* x0, float* x_out, int iters, int B, int T,
+                hipStream_t st) {
+    int rc = ensure_table(p);
+    if (!rc) rc = ensure_buffers(p);
+    if (rc) return rc;
+    const int G = pick_run_length(p, B, T);
+    const int nruns = (T + G - 1) / G;
+    const long long L = gl_len(p->n_fft, p->hop, T);
+    FastArgs a = {};
+    a.mag = mag;
+    a.tab = p->d_fast_tab;
+    a.H = p->hop;
+    a.T = T;
+    a.G = G;
+    a.nruns = nruns;
+    a.L = L;
+    a.g_in = G;
+    a.nruns_in = nruns;
+    const float* src = x0;
+    const float* src_tail = nullptr;
+    for (int it = 0; it < iters; ++it) {
+        const bool last = (it == iters - 1);
+        float* dst = (it & 1) ? p->d_xb : p->d_xa;
+        float* dst_tail = (it & 1) ? p->d_tail_b : p->d_tail_a;
+        if (last && nruns == 1) dst = x_out;     // single run: no tails, write the result directly
+        a.x_in = src;
+        a.x_stride = L;
+        a.tail_in = src_tail;
+        a.x_out = dst;
+        a.tail_out = dst_tail;
+        rc = launch<MODE_GL>(a, B, st);
+        if (rc) return rc;
+        src = dst;
+        src_tail = (nruns > 1) ? dst_tail : nullptr;
+    }
+    if (nruns > 1) return fold(p, src, src_tail, x_out, B, T, G, nruns, st);
+    return 0;
 }

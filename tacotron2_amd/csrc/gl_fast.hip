@@ -26,6 +26,7 @@
 // Replaces audio_utilities.py:91-92 (frame*window, rfft), :181-183 (projection),
 // :112-113 (irfft, window, overlap-add) per iteration of :178-187.
 #include <math.h>
+#include <stdlib.h>
 
 #include <vector>
 
@@ -70,6 +71,10 @@ __device__ __forceinline__ v2f ctw(v2f a, v2f w) { return INV ? cmulc(a, w) : cm
 __device__ __forceinline__ v2f mul_mi(v2f a) { v2f r; r.x = a.y; r.y = -a.x; return r; }   // -i*a
 __device__ __forceinline__ v2f mul_pi(v2f a) { v2f r; r.x = -a.y; r.y = a.x; return r; }   // +i*a
 __device__ __forceinline__ v2f cconj(v2f a) { v2f r; r.x = a.x; r.y = -a.y; return r; }
+
+// by-value select: `c ? z[i] : z[j]` on array lvalues would become a select of ADDRESSES
+// (dynamic register indexing); passing by value keeps it a v_cndmask on data
+__device__ __forceinline__ v2f sel(bool c, v2f a, v2f b) { v2f r; r.x = c ? a.x : b.x; r.y = c ? a.y : b.y; return r; }
 
 template <bool INV>
 __device__ __forceinline__ void dft4(v2f& a0, v2f& a1, v2f& a2, v2f& a3) {
@@ -313,11 +318,11 @@ __global__ void __launch_bounds__(64) k_fast2048(FastArgs p) {
             v2f P[9], Q[9];
             if (MODE != MODE_ISTFT) {
                 P[0] = z[0];
-                Q[0] = l0 ? z[0] : z[15];
+                Q[0] = sel(l0, z[0], z[15]);
 #pragma unroll
-                for (int c = 1; c < 4; ++c) { P[c] = z[c]; Q[c] = l0 ? z[8 - c] : z[15 - c]; }
+                for (int c = 1; c < 4; ++c) { P[c] = z[c]; Q[c] = sel(l0, z[8 - c], z[15 - c]); }
 #pragma unroll
-                for (int c = 4; c < 8; ++c) { P[c] = l0 ? z[8 + c - 4] : z[c]; Q[c] = l0 ? z[8 + 11 - c] : z[15 - c]; }
+                for (int c = 4; c < 8; ++c) { P[c] = sel(l0, z[8 + c - 4], z[c]); Q[c] = sel(l0, z[8 + 11 - c], z[15 - c]); }
                 P[8] = z[4];
                 Q[8] = z[4];
             }
@@ -349,14 +354,14 @@ __global__ void __launch_bounds__(64) k_fast2048(FastArgs p) {
             z[0] = Pn[0];
 #pragma unroll
             for (int c = 1; c < 4; ++c) z[c] = Pn[c];
-            z[4] = l0 ? Pn[8] : Pn[4];
+            z[4] = sel(l0, Pn[8], Pn[4]);
 #pragma unroll
-            for (int c = 5; c < 8; ++c) z[c] = l0 ? Qn[8 - c] : Pn[c];
+            for (int c = 5; c < 8; ++c) z[c] = sel(l0, Qn[8 - c], Pn[c]);
             // B[i], i = 0..7
 #pragma unroll
-            for (int i = 0; i < 4; ++i) z[8 + i] = l0 ? Pn[4 + i] : Qn[7 - i];
+            for (int i = 0; i < 4; ++i) z[8 + i] = sel(l0, Pn[4 + i], Qn[7 - i]);
 #pragma unroll
-            for (int i = 4; i < 8; ++i) z[8 + i] = l0 ? Qn[11 - i] : Qn[7 - i];
+            for (int i = 4; i < 8; ++i) z[8 + i] = sel(l0, Qn[11 - i], Qn[7 - i]);
         }
 
         // ---- inverse pass 3': inverse DFT-8 over c -> a, back through exchange 2 -------------------------
@@ -423,6 +428,272 @@ __global__ void __launch_bounds__(64) k_fast2048(FastArgs p) {
     }
 }
 
+
+// =====================================================================================
+// Register-ring variant for hops that are a multiple of 128 samples (H = 128*HS).
+//
+// Lane l holds frame samples 2(l+64j), 2(l+64j)+1 in register j, so a hop of 128*HS
+// samples is a shift by HS registers: the un-windowed input frame (xraw) and the
+// overlap-add accumulator (accr) both live in registers and slide by HS rows per
+// frame.  Per frame the wave loads HS new rows (prefetched one frame ahead), stores
+// HS finished rows, and uses LDS only for the four FFT transposes (9 KB per wave).
+// Window and twiddles are re-read from a 32 KB L1/L2-resident table at their use
+// sites to keep the register budget at 3 waves per SIMD.
+// =====================================================================================
+constexpr int kEx2StrideInv = 132;   // inverse exchange-2 stride: conflict-free b64 reads
+static_assert(kScratch >= 8 * kEx2StrideInv, "scratch too small");
+
+constexpr int kT2Win = 0;       // 16: (w[2(l+64j)], w[2(l+64j)+1])
+constexpr int kT2WinSc = 16;    // 16: the same / 1024
+constexpr int kT2Tw1 = 32;      // 15: W1024^(l*k2), k2 = 1..15
+constexpr int kT2Tw2 = 47;      // 7:  W64^(a*d), d = 1..7
+constexpr int kT2Twp = 54;      // 9:  W2048^(kP[u])
+constexpr int kT2Entries = 63;
+
+__device__ __forceinline__ void fft_forward_1024(v2f* z, v2f* ex, int l, int a3, int g3, int kloB,
+                                                 const v2f* __restrict__ tabl) {
+    dft16<false>(z);
+#pragma unroll
+    for (int k2 = 1; k2 < 16; ++k2) z[k2] = cmul(z[k2], tabl[(kT2Tw1 + k2 - 1) * 64]);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) ex[k2 * kEx1Stride + l] = z[k2];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int bb = 0; bb < 8; ++bb) z[8 * h + bb] = ex[(g3 + 8 * h) * kEx1Stride + a3 + 8 * bb];
+    dft8<false>(z);
+    dft8<false>(z + 8);
+#pragma unroll
+    for (int d = 1; d < 8; ++d) {
+        v2f w = tabl[(kT2Tw2 + d - 1) * 64];
+        z[d] = cmul(z[d], w);
+        z[8 + d] = cmul(z[8 + d], w);
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int d = 0; d < 8; ++d) ex[a3 * kEx2Stride + 16 * d + g3 + 8 * h] = z[8 * h + d];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int a = 0; a < 8; ++a) { z[a] = ex[a * kEx2Stride + l]; z[8 + a] = ex[a * kEx2Stride + kloB]; }
+    dft8<false>(z);
+    dft8<false>(z + 8);
+}
+
+__device__ __forceinline__ void fft_inverse_1024(v2f* z, v2f* ex, int l, int a3, int g3, int kloB,
+                                                 const v2f* __restrict__ tabl) {
+    dft8<true>(z);
+    dft8<true>(z + 8);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int a = 0; a < 8; ++a) { ex[a * kEx2StrideInv + l] = z[a]; ex[a * kEx2StrideInv + kloB] = z[8 + a]; }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int d = 0; d < 8; ++d) z[8 * h + d] = ex[a3 * kEx2StrideInv + 16 * d + g3 + 8 * h];
+#pragma unroll
+    for (int d = 1; d < 8; ++d) {
+        v2f w = tabl[(kT2Tw2 + d - 1) * 64];
+        z[d] = cmulc(z[d], w);
+        z[8 + d] = cmulc(z[8 + d], w);
+    }
+    dft8<true>(z);
+    dft8<true>(z + 8);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int bb = 0; bb < 8; ++bb) ex[(g3 + 8 * h) * kEx1Stride + a3 + 8 * bb] = z[8 * h + bb];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) z[k2] = ex[k2 * kEx1Stride + l];
+#pragma unroll
+    for (int k2 = 1; k2 < 16; ++k2) z[k2] = cmulc(z[k2], tabl[(kT2Tw1 + k2 - 1) * 64]);
+    dft16<true>(z);
+}
+
+// rfft split + magnitude projection + inverse split on the 9 lane-local mirror pairs.
+// lanes >= 1: P[c] = A[c], Q[c] = B[7-c]; lane 0 pairs inside its own two butterflies
+// (oracle/sim_fast2048.py); unit 8 is lane 0's self-mirrored bin 512 (a dummy elsewhere).
+__device__ __forceinline__ void middle_project(v2f* z, bool l0, const float* m_lo, const float* m_hi,
+                                               const v2f* __restrict__ tabl) {
+    v2f P[9], Q[9];
+    P[0] = z[0];
+    Q[0] = sel(l0, z[0], z[15]);
+#pragma unroll
+    for (int c = 1; c < 4; ++c) { P[c] = z[c]; Q[c] = sel(l0, z[8 - c], z[15 - c]); }
+#pragma unroll
+    for (int c = 4; c < 8; ++c) { P[c] = sel(l0, z[8 + c - 4], z[c]); Q[c] = sel(l0, z[8 + 11 - c], z[15 - c]); }
+    P[8] = z[4];
+    Q[8] = z[4];
+#pragma unroll
+    for (int u = 0; u < 9; ++u) {
+        v2f w = tabl[(kT2Twp + u) * 64];
+        v2f Xk, Xmk;
+        pair_fwd(P[u], Q[u], w, Xk, Xmk);
+        Xk = project(Xk, m_lo[u]);
+        Xmk = project(Xmk, m_hi[u]);
+        pair_inv(Xk, Xmk, w, P[u], Q[u]);
+    }
+    z[0] = P[0];
+#pragma unroll
+    for (int c = 1; c < 4; ++c) z[c] = P[c];
+    z[4] = sel(l0, P[8], P[4]);
+#pragma unroll
+    for (int c = 5; c < 8; ++c) z[c] = sel(l0, Q[8 - c], P[c]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) z[8 + i] = sel(l0, P[4 + i], Q[7 - i]);
+#pragma unroll
+    for (int i = 4; i < 8; ++i) z[8 + i] = sel(l0, Q[11 - i], Q[7 - i]);
+}
+
+struct AlignedArgs {
+    const float* x_in;      // [B][L]
+    const float* tail_in;   // [B][nruns][N-H] or null (same run geometry as this launch)
+    const float* mag;       // [B][T][F]
+    float* x_out;           // [B][L]
+    float* tail_out;        // [B][nruns][N-H]
+    const v2f* tab;         // [kT2Entries][64]
+    int T, G, nruns;
+    long long L;
+};
+
+#ifndef GL_RR_WAVES
+#define GL_RR_WAVES 4
+#endif
+#ifndef GL_RR_OCC
+#define GL_RR_OCC 2
+#endif
+constexpr int kRRWaves = GL_RR_WAVES;        // waves per workgroup; they only share the constant table
+
+template <int HS>
+__global__ void __launch_bounds__(64 * kRRWaves, GL_RR_OCC) k_gl2048_regring(AlignedArgs p) {
+    // one LDS array (table + per-wave transpose scratch): 32 KB + 4 x 9 KB = 69 KB -> 2 WG / CU
+    __shared__ __attribute__((aligned(16))) v2f smem[kT2Entries * 64 + kRRWaves * kScratch];
+    constexpr int H = 128 * HS;
+    constexpr int OVR = 16 - HS;                 // rows shared with the next frame / next run
+    constexpr int ovl = kN - H;
+    const int l = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform
+    const int b = blockIdx.y;
+    const int run = blockIdx.x * kRRWaves + wave;
+    for (int i = threadIdx.x; i < kT2Entries * 64; i += 64 * kRRWaves) smem[i] = p.tab[i];
+    __syncthreads();
+    if (run >= p.nruns) return;                  // wave-uniform; no barrier after this point
+    v2f* ex = smem + kT2Entries * 64 + wave * kScratch;
+    const v2f* tabl = smem + l;
+    const int T = p.T;
+    const int f0 = run * p.G;
+    const int f1 = min(f0 + p.G, T);
+    const int a3 = l & 7, g3 = l >> 3;
+    const int kloB = l ? 128 - l : 64;
+    const bool l0 = (l == 0);
+    const int gh = p.G * H;
+    const int nruns = p.nruns;
+
+    const float* xr = p.x_in + (long long)b * p.L + 2 * l;
+    const float* tr = p.tail_in ? p.tail_in + (long long)b * nruns * ovl + 2 * l : nullptr;
+
+    // Row of 128 samples starting `rel` samples after this run's first sample.  The run that
+    // produced it may have left part of its sum in a tail: the previous run's tail covers the
+    // first N-H samples of this run's region, this run's own tail the first N-H of the next.
+    const bool has_tail = (p.tail_in != nullptr);
+    const int own_prev = (run >= 1) ? 1 : 0;
+    const bool has_next = (run + 1 < nruns);
+    const float* xrun = xr + (long long)f0 * H;
+    const float* t_prev = tr ? tr + (long long)(run - own_prev) * ovl : nullptr;
+    const float* t_own = tr ? tr + (long long)run * ovl : nullptr;
+    auto load_row = [&](int rel) -> v2f {
+        v2f v = *reinterpret_cast<const v2f*>(xrun + rel);
+        if (has_tail) {
+            const int rel_next = rel - gh;
+            if (has_next && rel_next >= 0) {
+                if (rel_next < ovl) v += *reinterpret_cast<const v2f*>(t_own + rel_next);
+            } else if (own_prev && rel < ovl) {
+                v += *reinterpret_cast<const v2f*>(t_prev + rel);
+            }
+        }
+        return v;
+    };
+
+    v2f xraw[16], accr[16];
+    {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            xraw[j] = load_row(128 * j);
+            accr[j] = (v2f){0.0f, 0.0f};
+        }
+    }
+
+    for (int n = f0; n < f1; ++n) {
+        const long long sn = (long long)n * H;
+        const int lt = l;
+
+        // prefetch the HS rows the next frame adds
+        const bool more = (n + 1 < f1);
+        v2f xnew[HS];
+#pragma unroll
+        for (int jj = 0; jj < HS; ++jj) xnew[jj] = (v2f){0.0f, 0.0f};
+        if (more) {
+#pragma unroll
+            for (int jj = 0; jj < HS; ++jj) xnew[jj] = load_row((n - f0) * H + kN + 128 * jj);
+        }
+        // this frame's magnitudes at the lane's 9 mirror pairs
+        float m_lo[9], m_hi[9];
+        {
+            const float* mrow = p.mag + ((long long)b * T + n) * (kM + 1);
+            const int bA = lt, bB = lt ? lt : -448;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                int k = (u < 4 ? bA : bB) + 128 * u;
+                m_lo[u] = mrow[k];
+                m_hi[u] = mrow[kM - k];
+            }
+            m_lo[8] = mrow[512];
+            m_hi[8] = m_lo[8];
+        }
+
+        v2f z[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) z[j] = xraw[j] * tabl[(kT2Win + j) * 64];
+        fft_forward_1024(z, ex, l, a3, g3, kloB, tabl);
+        middle_project(z, l0, m_lo, m_hi, tabl);
+        fft_inverse_1024(z, ex, l, a3, g3, kloB, tabl);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            v2f w = tabl[(kT2WinSc + j) * 64];
+            accr[j].x = fmaf(z[j].x, w.x, accr[j].x);
+            accr[j].y = fmaf(z[j].y, w.y, accr[j].y);
+        }
+        // rows 0..HS-1 are complete: every sample is written exactly once
+        float* orow = p.x_out + (long long)b * p.L + sn + 2 * l;
+#pragma unroll
+        for (int jj = 0; jj < HS; ++jj) *reinterpret_cast<v2f*>(orow + 128 * jj) = accr[jj];
+#pragma unroll
+        for (int j = 0; j < OVR; ++j) { accr[j] = accr[j + HS]; xraw[j] = xraw[j + HS]; }
+#pragma unroll
+        for (int jj = 0; jj < HS; ++jj) { accr[OVR + jj] = (v2f){0.0f, 0.0f}; xraw[OVR + jj] = xnew[jj]; }
+    }
+
+    // partial sums of the N-H samples after the run's last frame
+    const long long se = (long long)f1 * H;
+    if (f1 == T) {
+        float* orow = p.x_out + (long long)b * p.L + se + 2 * l;
+#pragma unroll
+        for (int j = 0; j < OVR; ++j) *reinterpret_cast<v2f*>(orow + 128 * j) = accr[j];
+#pragma unroll
+        for (int jj = 0; jj < HS; ++jj) *reinterpret_cast<v2f*>(orow + 128 * (OVR + jj)) = (v2f){0.0f, 0.0f};
+    } else {
+        float* trow = p.tail_out + ((long long)b * nruns + run) * ovl + 2 * l;
+#pragma unroll
+        for (int j = 0; j < OVR; ++j) *reinterpret_cast<v2f*>(trow + 128 * j) = accr[j];
+    }
+}
+
 // x_out[s] = x_main[s] + tail of the previous run (final fold after the last iteration)
 __global__ void __launch_bounds__(256) k_fold_tails(const float* __restrict__ x_main, const float* __restrict__ tail,
                                                     float* __restrict__ x_out, long long L, int g_h, int nruns,
@@ -434,15 +705,34 @@ __global__ void __launch_bounds__(256) k_fold_tails(const float* __restrict__ x_
         fetch_x(x_main + (long long)b * L, tail + (long long)b * nruns * ovl, s, g_h, nruns, ovl);
 }
 
-int pick_run_length(const gl_plan* p, int B, int T) {
+// Frames per wave-run.  A run costs its frames plus a fixed prologue/epilogue (ring fill,
+// tail write, ~1.5 frame-times); the launch finishes after ceil(runs / resident waves)
+// rounds, so choose the G that minimises rounds * (G + overhead).  G*H >= N-H keeps the
+// number of runs that touch one sample at two.
+int pick_run_length(const gl_plan* p, int B, int T, int waves_per_cu) {
     const int N = p->n_fft, H = p->hop;
-    int g_min = (N - H + H - 1) / H;            // G*H >= N-H: at most two runs touch a sample
+    int g_min = (N - H + H - 1) / H;
     if (g_min < 1) g_min = 1;
-    int G = 16;
-    if (G < g_min) G = g_min;
-    if (G > T) G = T;
-    (void)B;
-    return G;
+    if (const char* e = getenv("GL_RUN_FRAMES")) {
+        int G = atoi(e);
+        if (G < g_min) G = g_min;
+        return G > T ? T : G;
+    }
+    if (T <= g_min) return T;
+    const long long slots = (long long)p->n_cu * waves_per_cu;
+    int best = g_min;
+    double best_cost = 1e300;
+    const int g_max = T < 96 ? T : 96;
+    for (int G = g_min; G <= g_max; ++G) {
+        const long long runs = (long long)B * ((T + G - 1) / G);
+        const long long rounds = (runs + slots - 1) / slots;
+        const double cost = (double)rounds * (G + 1.5);
+        if (cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && G > best)) {
+            best_cost = cost;
+            best = G;
+        }
+    }
+    return best;
 }
 
 int ensure_table(gl_plan* p) {
@@ -511,6 +801,94 @@ int fold(gl_plan* p, const float* x_main, const float* tail, float* x_out, int B
     return 0;
 }
 
+
+int ensure_table2(gl_plan* p) {
+    if (p->d_fast_tab2) return 0;
+    const int N = p->n_fft;
+    std::vector<float> tab((size_t)kT2Entries * 64 * 2, 0.0f);
+    const double pi = 3.14159265358979323846;
+    auto put = [&](int e, int l, double re, double im) {
+        tab[((size_t)e * 64 + l) * 2] = (float)re;
+        tab[((size_t)e * 64 + l) * 2 + 1] = (float)im;
+    };
+    auto Wre = [&](int n, long long k) { return cos(-2.0 * pi * (double)(k % n) / (double)n); };
+    auto Wim = [&](int n, long long k) { return sin(-2.0 * pi * (double)(k % n) / (double)n); };
+    for (int l = 0; l < 64; ++l) {
+        for (int j = 0; j < 16; ++j) {
+            int n0 = 2 * (l + 64 * j);
+            float w0 = (float)(0.5 - 0.5 * cos(2.0 * pi * n0 / (double)(N - 1)));
+            float w1 = (float)(0.5 - 0.5 * cos(2.0 * pi * (n0 + 1) / (double)(N - 1)));
+            put(kT2Win + j, l, w0, w1);
+            put(kT2WinSc + j, l, (double)w0 / kM, (double)w1 / kM);   // exact: power-of-two scale
+        }
+        for (int k2 = 1; k2 < 16; ++k2) put(kT2Tw1 + k2 - 1, l, Wre(1024, (long long)l * k2), Wim(1024, (long long)l * k2));
+        for (int d = 1; d < 8; ++d) put(kT2Tw2 + d - 1, l, Wre(64, (long long)(l & 7) * d), Wim(64, (long long)(l & 7) * d));
+        for (int u = 0; u < 9; ++u) {
+            int k = (u == 8) ? 512 : (l ? l + 128 * u : (u < 4 ? 128 * u : 64 + 128 * (u - 4)));
+            put(kT2Twp + u, l, Wre(2048, k), Wim(2048, k));
+        }
+    }
+    int rc = gl_plan_alloc(p, (void**)&p->d_fast_tab2, tab.size() * sizeof(float));
+    if (rc) return rc;
+    GL_HIP_CHECK(hipMemcpy(p->d_fast_tab2, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+bool regring_ok(const gl_plan* p, const void* a, const void* b) {
+    const int H = p->hop;
+    if (H % 128 != 0) return false;
+    const int hs = H / 128;
+    if (hs != 1 && hs != 2 && hs != 4 && hs != 8) return false;
+    return (((uintptr_t)a | (uintptr_t)b) & 7) == 0;
+}
+
+int launch_regring(const gl_plan* p, const AlignedArgs& a, int B, hipStream_t st) {
+    dim3 grid((a.nruns + kRRWaves - 1) / kRRWaves, B);
+    dim3 block(64 * kRRWaves);
+    switch (p->hop / 128) {
+        case 1: hipLaunchKernelGGL(k_gl2048_regring<1>, grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL(k_gl2048_regring<2>, grid, block, 0, st, a); break;
+        case 4: hipLaunchKernelGGL(k_gl2048_regring<4>, grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL(k_gl2048_regring<8>, grid, block, 0, st, a); break;
+    }
+    GL_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int run_regring(gl_plan* p, const float* mag, const float* x0, float* x_out, int iters, int B, int T,
+                hipStream_t st) {
+    int rc = ensure_table2(p);
+    if (!rc) rc = ensure_buffers(p);
+    if (rc) return rc;
+    const int G = pick_run_length(p, B, T, 2 * kRRWaves);
+    const int nruns = (T + G - 1) / G;
+    AlignedArgs a = {};
+    a.mag = mag;
+    a.tab = reinterpret_cast<const v2f*>(p->d_fast_tab2);
+    a.T = T;
+    a.G = G;
+    a.nruns = nruns;
+    a.L = gl_len(p->n_fft, p->hop, T);
+    const float* src = x0;
+    const float* src_tail = nullptr;
+    for (int it = 0; it < iters; ++it) {
+        const bool last = (it == iters - 1);
+        float* dst = (it & 1) ? p->d_xb : p->d_xa;
+        float* dst_tail = (it & 1) ? p->d_tail_b : p->d_tail_a;
+        if (last && nruns == 1) dst = x_out;
+        a.x_in = src;
+        a.tail_in = src_tail;
+        a.x_out = dst;
+        a.tail_out = dst_tail;
+        rc = launch_regring(p, a, B, st);
+        if (rc) return rc;
+        src = dst;
+        src_tail = (nruns > 1) ? dst_tail : nullptr;
+    }
+    if (nruns > 1) return fold(p, src, src_tail, x_out, B, T, G, nruns, st);
+    return 0;
+}
+
 }  // namespace
 
 bool gl_fast_supported(const gl_plan* p) { return p->n_fft == kN && p->hop <= kN && p->hop >= 1; }
@@ -525,7 +903,7 @@ int gl_fast_stft(gl_plan* p, const float* x, long long x_stride, float* S, int B
     a.tab = p->d_fast_tab;
     a.H = p->hop;
     a.T = T;
-    a.G = pick_run_length(p, B, T);
+    a.G = pick_run_length(p, B, T, 4);
     a.nruns = (T + a.G - 1) / a.G;
     a.L = gl_len(p->n_fft, p->hop, T);
     return launch<MODE_STFT>(a, B, st);
@@ -540,7 +918,7 @@ int gl_fast_istft(gl_plan* p, const float* S, float* y, int B, int T, hipStream_
     a.tab = p->d_fast_tab;
     a.H = p->hop;
     a.T = T;
-    a.G = pick_run_length(p, B, T);
+    a.G = pick_run_length(p, B, T, 4);
     a.nruns = (T + a.G - 1) / a.G;
     a.L = gl_len(p->n_fft, p->hop, T);
     a.x_out = (a.nruns > 1) ? p->d_xa : y;
@@ -552,10 +930,11 @@ int gl_fast_istft(gl_plan* p, const float* S, float* y, int B, int T, hipStream_
 
 int gl_fast_run(gl_plan* p, const float* mag, const float* x0, float* x_out, int iters, int B, int T,
                 hipStream_t st) {
+    if (p->path == 0 && regring_ok(p, x0, x_out)) return run_regring(p, mag, x0, x_out, iters, B, T, st);
     int rc = ensure_table(p);
     if (!rc) rc = ensure_buffers(p);
     if (rc) return rc;
-    const int G = pick_run_length(p, B, T);
+    const int G = pick_run_length(p, B, T, 4);
     const int nruns = (T + G - 1) / G;
     const long long L = gl_len(p->n_fft, p->hop, T);
     FastArgs a = {};

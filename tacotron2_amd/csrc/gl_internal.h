@@ -22,6 +22,8 @@ struct gl_plan {
     float* d_tail_a;  // fused path: per-run partial-sum tails (lazy)
     float* d_tail_b;
     float* d_fast_tab;  // fused path constant tables (lazy)
+    float* d_fast_tab2; // register-ring kernel constant table (lazy)
+    float* d_xc;        // third signal buffer (lazy)
     unsigned* d_peaks;  // [max_B] bit patterns of max|x|
     long long bytes;
 };
@@ -72,18 +74,15 @@ __device__ __forceinline__ float2 c_mulc(float2 a, float2 b) {  // a * conj(b)
 }
 __device__ __forceinline__ float2 c_conj(float2 a) { return make_float2(a.x, -a.y); }
 
-// Magnitude projection, audio_utilities.py:181-183: mag * exp(1j*angle(X));
-// np.angle(0) == 0 so a zero bin becomes (mag, 0).
-// Fused form X * mag * rsqrt(|X|^2); bins whose |X|^2 would be subnormal in fp32
-// are rescaled by 2^60 first so the phase of tiny-but-nonzero bins is kept.
+// Magnitude projection, audio_utilities.py:181-183: mag * exp(1j*angle(X)), computed as
+// X * (mag * rsq(|X|^2)) with one v_rsq_f32.  np.angle(0) == 0, so a zero bin becomes
+// (mag, 0); bins whose |X|^2 is below 1e-36 (|X| < 1e-18, at the edge of fp32's normal
+// range, 11 orders of magnitude under the fp32 rounding noise of a unit-scale frame)
+// are treated as zero.  Branch-free.
+#define GL_TINY_R2 1e-36f
 __device__ __forceinline__ float2 gl_project(float2 X, float m) {
-    float r2 = X.x * X.x + X.y * X.y;
-    if (__builtin_expect(r2 < 1e-30f, 0)) {
-        X.x *= 1.152921504606846976e18f;
-        X.y *= 1.152921504606846976e18f;
-        r2 = X.x * X.x + X.y * X.y;
-        if (!(r2 > 0.0f)) return make_float2(m, 0.0f);
-    }
-    float s = m * rsqrtf(r2);
-    return make_float2(X.x * s, X.y * s);
+    const float r2 = fmaf(X.x, X.x, X.y * X.y);
+    const float s = m * __builtin_amdgcn_rsqf(fmaxf(r2, GL_TINY_R2));
+    const bool ok = r2 >= GL_TINY_R2;
+    return make_float2(ok ? X.x * s : m, ok ? X.y * s : 0.0f);
 }

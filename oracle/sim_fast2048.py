@@ -171,5 +171,71 @@ def main():
     print("projection + irfft ok")
 
 
+# ---------------------------------------------------------------------------------------
+# n_fft = 1024: two real frames per 1024-point complex FFT (z = frame_a + i*frame_b).
+# Same forward/inverse lane maps; the split needs no twiddle:
+#   S = Z[k] + conj(Z[M-k]) = 2 Xa[k],  D = Z[k] - conj(Z[M-k]) = 2i Xb[k]
+#   Z'[k] = S*sa + D*sb,  Z'[M-k] = conj(S*sa - D*sb),  sa = ma/|S|, sb = mb/|D|
+# with the magnitude index min(k, M-k); zero S -> (ma, 0), zero D -> i*(mb, 0).
+# ---------------------------------------------------------------------------------------
+def middle_two_frames(ZA, ZB, mag_a, mag_b, a_zero=False, b_zero=False):
+    M = 1024
+    ZA2 = np.zeros_like(ZA)
+    ZB2 = np.zeros_like(ZB)
+    for l in range(64):
+        if l:
+            P = [(0, c) for c in range(8)]
+            Q = [(1, 7 - c) for c in range(8)]
+            kP = [l + 128 * c for c in range(8)]
+            extra = None
+        else:
+            P = [(0, 0), (0, 1), (0, 2), (0, 3), (1, 0), (1, 1), (1, 2), (1, 3)]
+            Q = [(0, 0), (0, 7), (0, 6), (0, 5), (1, 7), (1, 6), (1, 5), (1, 4)]
+            kP = [0, 128, 256, 384, 64, 192, 320, 448]
+            extra = ((0, 4), (0, 4), 512)
+        units = list(zip(P, Q, kP)) + ([extra] if extra else [])
+        for (pw, pi), (qw, qi), k in units:
+            src = (ZA, ZB)
+            zk, zm = src[pw][l, pi], src[qw][l, qi]
+            kk = min(k, M - k)
+            S = zk + np.conj(zm)
+            D = zk - np.conj(zm)
+            if a_zero:      # an all-zero input frame is forced to an exactly zero spectrum
+                S = 0j      # (rounding noise of the partner frame must not set its phase)
+            if b_zero:
+                D = 0j
+            Ya = S * (mag_a[kk] / abs(S)) if abs(S) > 0 else complex(mag_a[kk], 0)
+            Yb = D * (mag_b[kk] / abs(D)) if abs(D) > 0 else complex(0, mag_b[kk])
+            dst = (ZA2, ZB2)
+            dst[qw][l, qi] = np.conj(Ya - Yb)
+            dst[pw][l, pi] = Ya + Yb
+    return ZA2, ZB2
+
+
+def check_two_frames():
+    rng = np.random.default_rng(3)
+    N = 1024
+    win = np.hanning(N)
+    fa, fb = rng.standard_normal(N), rng.standard_normal(N)
+    z = win * fa + 1j * (win * fb)
+    ZA, ZB = forward_2048(z)
+    mag_a, mag_b = np.abs(rng.standard_normal(513)), np.abs(rng.standard_normal(513))
+    ZA2, ZB2 = middle_two_frames(ZA, ZB, mag_a, mag_b)
+    z2 = inverse_2048(ZA2, ZB2) / 1024
+    ya = np.fft.irfft(mag_a * np.exp(1j * np.angle(np.fft.rfft(win * fa))))
+    yb = np.fft.irfft(mag_b * np.exp(1j * np.angle(np.fft.rfft(win * fb))))
+    assert np.max(np.abs(z2.real - ya)) < 1e-9, np.max(np.abs(z2.real - ya))
+    assert np.max(np.abs(z2.imag - yb)) < 1e-9, np.max(np.abs(z2.imag - yb))
+    # zero input frame b -> phase 0 everywhere for b
+    z = win * fa + 0j
+    ZA, ZB = forward_2048(z)
+    ZA2, ZB2 = middle_two_frames(ZA, ZB, mag_a, mag_b, b_zero=True)
+    z2 = inverse_2048(ZA2, ZB2) / 1024
+    assert np.max(np.abs(z2.imag - np.fft.irfft(mag_b.astype(complex)))) < 1e-9
+    assert np.max(np.abs(z2.real - ya)) < 1e-9
+    print("two-frames-per-FFT split (n_fft 1024) ok")
+
+
 if __name__ == "__main__":
     main()
+    check_two_frames()

@@ -440,6 +440,9 @@ __global__ void __launch_bounds__(64) k_fast2048(FastArgs p) {
 // Window and twiddles are re-read from a 32 KB L1/L2-resident table at their use
 // sites to keep the register budget at 3 waves per SIMD.
 // =====================================================================================
+#ifndef GL_ABL
+#define GL_ABL 0   // timing experiments only: 1 skip LDS transposes, 2 skip projection step, 4 constant twiddles
+#endif
 constexpr int kEx2StrideInv = 132;   // inverse exchange-2 stride: conflict-free b64 reads
 static_assert(kScratch >= 8 * kEx2StrideInv, "scratch too small");
 
@@ -455,6 +458,7 @@ __device__ __forceinline__ void fft_forward_1024(v2f* z, v2f* ex, int l, int a3,
     dft16<false>(z);
 #pragma unroll
     for (int k2 = 1; k2 < 16; ++k2) z[k2] = cmul(z[k2], tabl[(kT2Tw1 + k2 - 1) * 64]);
+    if (!(GL_ABL & 1)) {
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int k2 = 0; k2 < 16; ++k2) ex[k2 * kEx1Stride + l] = z[k2];
@@ -463,6 +467,7 @@ __device__ __forceinline__ void fft_forward_1024(v2f* z, v2f* ex, int l, int a3,
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int bb = 0; bb < 8; ++bb) z[8 * h + bb] = ex[(g3 + 8 * h) * kEx1Stride + a3 + 8 * bb];
+    }
     dft8<false>(z);
     dft8<false>(z + 8);
 #pragma unroll
@@ -471,6 +476,7 @@ __device__ __forceinline__ void fft_forward_1024(v2f* z, v2f* ex, int l, int a3,
         z[d] = cmul(z[d], w);
         z[8 + d] = cmul(z[8 + d], w);
     }
+    if (!(GL_ABL & 1)) {
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -479,6 +485,7 @@ __device__ __forceinline__ void fft_forward_1024(v2f* z, v2f* ex, int l, int a3,
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int a = 0; a < 8; ++a) { z[a] = ex[a * kEx2Stride + l]; z[8 + a] = ex[a * kEx2Stride + kloB]; }
+    }
     dft8<false>(z);
     dft8<false>(z + 8);
 }
@@ -487,6 +494,7 @@ __device__ __forceinline__ void fft_inverse_1024(v2f* z, v2f* ex, int l, int a3,
                                                  const v2f* __restrict__ tabl) {
     dft8<true>(z);
     dft8<true>(z + 8);
+    if (!(GL_ABL & 1)) {
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int a = 0; a < 8; ++a) { ex[a * kEx2StrideInv + l] = z[a]; ex[a * kEx2StrideInv + kloB] = z[8 + a]; }
@@ -495,6 +503,7 @@ __device__ __forceinline__ void fft_inverse_1024(v2f* z, v2f* ex, int l, int a3,
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int d = 0; d < 8; ++d) z[8 * h + d] = ex[a3 * kEx2StrideInv + 16 * d + g3 + 8 * h];
+    }
 #pragma unroll
     for (int d = 1; d < 8; ++d) {
         v2f w = tabl[(kT2Tw2 + d - 1) * 64];
@@ -503,6 +512,7 @@ __device__ __forceinline__ void fft_inverse_1024(v2f* z, v2f* ex, int l, int a3,
     }
     dft8<true>(z);
     dft8<true>(z + 8);
+    if (!(GL_ABL & 1)) {
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -511,6 +521,7 @@ __device__ __forceinline__ void fft_inverse_1024(v2f* z, v2f* ex, int l, int a3,
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int k2 = 0; k2 < 16; ++k2) z[k2] = ex[k2 * kEx1Stride + l];
+    }
 #pragma unroll
     for (int k2 = 1; k2 < 16; ++k2) z[k2] = cmulc(z[k2], tabl[(kT2Tw1 + k2 - 1) * 64]);
     dft16<true>(z);
@@ -650,8 +661,8 @@ __global__ void __launch_bounds__(64 * kRRWaves, GL_RR_OCC) k_gl2048_regring(Ali
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 int k = (u < 4 ? bA : bB) + 128 * u;
-                m_lo[u] = mrow[k];
-                m_hi[u] = mrow[kM - k];
+                m_lo[u] = (GL_ABL & 8) ? 1.0f + k : mrow[k];
+                m_hi[u] = (GL_ABL & 8) ? 2.0f + k : mrow[kM - k];
             }
             m_lo[8] = mrow[512];
             m_hi[8] = m_lo[8];
@@ -661,7 +672,7 @@ __global__ void __launch_bounds__(64 * kRRWaves, GL_RR_OCC) k_gl2048_regring(Ali
 #pragma unroll
         for (int j = 0; j < 16; ++j) z[j] = xraw[j] * tabl[(kT2Win + j) * 64];
         fft_forward_1024(z, ex, l, a3, g3, kloB, tabl);
-        middle_project(z, l0, m_lo, m_hi, tabl);
+        if (!(GL_ABL & 2)) middle_project(z, l0, m_lo, m_hi, tabl);
         fft_inverse_1024(z, ex, l, a3, g3, kloB, tabl);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -845,11 +856,12 @@ bool regring_ok(const gl_plan* p, const void* a, const void* b) {
 int launch_regring(const gl_plan* p, const AlignedArgs& a, int B, hipStream_t st) {
     dim3 grid((a.nruns + kRRWaves - 1) / kRRWaves, B);
     dim3 block(64 * kRRWaves);
+    static const size_t pad = getenv("GL_RR_PADLDS") ? (size_t)atoi(getenv("GL_RR_PADLDS")) : 0;  // experiments
     switch (p->hop / 128) {
-        case 1: hipLaunchKernelGGL(k_gl2048_regring<1>, grid, block, 0, st, a); break;
-        case 2: hipLaunchKernelGGL(k_gl2048_regring<2>, grid, block, 0, st, a); break;
-        case 4: hipLaunchKernelGGL(k_gl2048_regring<4>, grid, block, 0, st, a); break;
-        default: hipLaunchKernelGGL(k_gl2048_regring<8>, grid, block, 0, st, a); break;
+        case 1: hipLaunchKernelGGL(k_gl2048_regring<1>, grid, block, pad, st, a); break;
+        case 2: hipLaunchKernelGGL(k_gl2048_regring<2>, grid, block, pad, st, a); break;
+        case 4: hipLaunchKernelGGL(k_gl2048_regring<4>, grid, block, pad, st, a); break;
+        default: hipLaunchKernelGGL(k_gl2048_regring<8>, grid, block, pad, st, a); break;
     }
     GL_HIP_CHECK(hipGetLastError());
     return 0;

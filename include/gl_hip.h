@@ -98,6 +98,14 @@ int gl_run(gl_plan* plan, const float* mag, const float* x0, float* x_out,
  * 1 = force the generic (any power-of-two N) kernels.  For tests/benchmarks.   */
 int gl_plan_set_path(gl_plan* plan, int path);
 
+/* Frames each wavefront of the fused kernels processes in one run (0 = automatic: chosen from
+ * B, T and the CU count to fill the GPU in whole rounds).  Results are bit-reproducible for a
+ * given run length; overlap-add sums at run seams associate differently for different run
+ * lengths (last-bit differences), so pin it when outputs of different batch sizes -- e.g.
+ * per-GPU shards vs. one big batch -- must be bit-identical.  Values below ceil((N-H)/H) are
+ * raised to it.  No counterpart in the reference (a property of the GPU work split).          */
+int gl_plan_set_run_frames(gl_plan* plan, int frames);
+
 /* Device standard-normal fill (Philox4x32-10 + Box-Muller), for throughput runs
  * where bit-parity with numpy's MT19937 stream (audio_utilities.py:176) is not
  * needed.  out : [n] fp32.  Deterministic in (seed, index).                     */

@@ -135,6 +135,12 @@ int gl_plan_set_path(gl_plan* p, int path) {
     return 0;
 }
 
+int gl_plan_set_run_frames(gl_plan* p, int frames) {
+    if (!p || frames < 0) return gl_set_error(GL_ERR_INVALID, "gl_plan_set_run_frames: bad argument");
+    p->run_frames = frames;
+    return 0;
+}
+
 static int check_call(const gl_plan* p, int B, int T, const char* who) {
     if (!p) return gl_set_error(GL_ERR_INVALID, "%s: plan is NULL", who);
     if (B < 1 || B > p->max_B) return gl_set_error(GL_ERR_INVALID, "%s: B=%d outside [1, %d]", who, B, p->max_B);
@@ -142,7 +148,7 @@ static int check_call(const gl_plan* p, int B, int T, const char* who) {
     return 0;
 }
 
-static bool use_fast(const gl_plan* p) { return p->path == 0 && gl_fast_supported(p); }
+static bool use_fast(const gl_plan* p, int op) { return p->path == 0 && gl_fast_supported(p, op); }
 
 int gl_stft(gl_plan* p, const float* x, long long x_stride, float* S, int B, int T, void* stream) {
     int rc = check_call(p, B, T, "gl_stft");
@@ -152,7 +158,7 @@ int gl_stft(gl_plan* p, const float* x, long long x_stride, float* S, int B, int
         return gl_set_error(GL_ERR_INVALID, "gl_stft: x_stride %lld shorter than (T-1)*H+N", x_stride);
     DeviceGuard guard(p->device);
     hipStream_t st = (hipStream_t)stream;
-    return use_fast(p) ? gl_fast_stft(p, x, x_stride, S, B, T, st) : gl_generic_stft(p, x, x_stride, S, B, T, st);
+    return use_fast(p, GL_FAST_OP_STFT) ? gl_fast_stft(p, x, x_stride, S, B, T, st) : gl_generic_stft(p, x, x_stride, S, B, T, st);
 }
 
 int gl_istft(gl_plan* p, const float* S, float* y, int B, int T, void* stream) {
@@ -161,7 +167,7 @@ int gl_istft(gl_plan* p, const float* S, float* y, int B, int T, void* stream) {
     if (!S || !y) return gl_set_error(GL_ERR_INVALID, "gl_istft: NULL buffer");
     DeviceGuard guard(p->device);
     hipStream_t st = (hipStream_t)stream;
-    return use_fast(p) ? gl_fast_istft(p, S, y, B, T, st) : gl_generic_istft(p, S, y, B, T, st);
+    return use_fast(p, GL_FAST_OP_ISTFT) ? gl_fast_istft(p, S, y, B, T, st) : gl_generic_istft(p, S, y, B, T, st);
 }
 
 int gl_mel_to_mag(gl_plan* p, const float* filterbank, const float* mel, float* mag, int n_mels, int B, int T,
@@ -182,7 +188,7 @@ int gl_run(gl_plan* p, const float* mag, const float* x0, float* x_out, int iter
     DeviceGuard guard(p->device);
     hipStream_t st = (hipStream_t)stream;
     if (iters == 0) return gl_copy_rows(x_out, x0, (long long)B * gl_len(p->n_fft, p->hop, T), st);
-    return use_fast(p) ? gl_fast_run(p, mag, x0, x_out, iters, B, T, st)
+    return use_fast(p, GL_FAST_OP_RUN) ? gl_fast_run(p, mag, x0, x_out, iters, B, T, st)
                        : gl_generic_run(p, mag, x0, x_out, iters, B, T, st);
 }
 

@@ -705,6 +705,198 @@ __global__ void __launch_bounds__(64 * kRRWaves, GL_RR_OCC) k_gl2048_regring(Ali
     }
 }
 
+
+// =====================================================================================
+// n_fft = 1024, any hop (the reference's params.py defaults are 1024 / 275).
+//
+// Two consecutive REAL frames ride one 1024-point COMPLEX FFT: z = frame_a + i*frame_b.
+// With S = Z[k] + conj(Z[M-k]) = 2*Xa[k] and D = Z[k] - conj(Z[M-k]) = 2i*Xb[k] the
+// projection of both frames is  Z'[k] = S*sa + D*sb,  Z'[M-k] = conj(S*sa - D*sb)
+// (sa = mag_a/|S|, sb = mag_b/|D|, magnitude index min(k, M-k)); no twiddle is needed
+// and the mirror pairs are lane-local in the same lane map as the 2048 kernels, so the
+// FFT core is shared (oracle/sim_fast2048.py: check_two_frames).  The real part of the
+// inverse transform is frame a's output, the imaginary part frame b's.
+// x and the overlap-add accumulator live in per-wave LDS rings (hop 275 is not a
+// multiple of the 64-sample register rows).
+// =====================================================================================
+constexpr int kN1 = 1024;
+constexpr int kP1Waves = 4;
+constexpr int kP1Ring = 2048;      // floats; >= N + H for every hop <= N
+constexpr int kP1WaveLds = kScratch + kP1Ring;   // v2f units per wave: transpose scratch + two float rings
+
+struct Pair1024Args {
+    const float* x_in;      // [B][L]
+    const float* tail_in;   // [B][nruns][N-H] or null (same run geometry as this launch)
+    const float* mag;       // [B][T][513]
+    float* x_out;           // [B][L]
+    float* tail_out;        // [B][nruns][N-H]
+    const v2f* tab;         // [kT2Entries][64]; window entries hold (w[l+64j], w[l+64j])
+    int H, T, G, nruns;
+    long long L;
+};
+
+// projection step for two frames sharing one complex spectrum (see header above)
+__device__ __forceinline__ void middle_two_frames(v2f* z, bool l0, const float* ma, const float* mb, float ka,
+                                                  float kb) {
+    v2f P[9], Q[9];
+    P[0] = z[0];
+    Q[0] = sel(l0, z[0], z[15]);
+#pragma unroll
+    for (int c = 1; c < 4; ++c) { P[c] = z[c]; Q[c] = sel(l0, z[8 - c], z[15 - c]); }
+#pragma unroll
+    for (int c = 4; c < 8; ++c) { P[c] = sel(l0, z[8 + c - 4], z[c]); Q[c] = sel(l0, z[8 + 11 - c], z[15 - c]); }
+    P[8] = z[4];
+    Q[8] = z[4];
+#pragma unroll
+    for (int u = 0; u < 9; ++u) {
+        v2f S, D;
+        S.x = (P[u].x + Q[u].x) * ka;  S.y = (P[u].y - Q[u].y) * ka;     // P + conj(Q), forced to 0 for an all-zero frame a
+        D.x = (P[u].x - Q[u].x) * kb;  D.y = (P[u].y + Q[u].y) * kb;     // P - conj(Q)
+        float2 ya = gl_project(make_float2(S.x, S.y), ma[u]);            // Xa' (zero bin -> (ma, 0))
+        float2 xb = gl_project(make_float2(D.y, -D.x), mb[u]);           // Xb' from Xb = -i*D/2
+        v2f Ya = {ya.x, ya.y};
+        v2f Yb = {-xb.y, xb.x};                                          // i*Xb'
+        P[u] = Ya + Yb;
+        v2f t = Ya - Yb;
+        Q[u].x = t.x;
+        Q[u].y = -t.y;
+    }
+    z[0] = P[0];
+#pragma unroll
+    for (int c = 1; c < 4; ++c) z[c] = P[c];
+    z[4] = sel(l0, P[8], P[4]);
+#pragma unroll
+    for (int c = 5; c < 8; ++c) z[c] = sel(l0, Q[8 - c], P[c]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) z[8 + i] = sel(l0, P[4 + i], Q[7 - i]);
+#pragma unroll
+    for (int i = 4; i < 8; ++i) z[8 + i] = sel(l0, Q[11 - i], Q[7 - i]);
+}
+
+__global__ void __launch_bounds__(64 * kP1Waves, 1) k_gl1024_pair(Pair1024Args p) {
+    // table 32 KB + 4 x (9 KB transpose scratch + 8 KB x ring + 8 KB accumulator ring) = 132 KB
+    __shared__ __attribute__((aligned(16))) v2f smem[kT2Entries * 64 + kP1Waves * kP1WaveLds];
+    const int l = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    const int run = blockIdx.x * kP1Waves + wave;
+    for (int i = threadIdx.x; i < kT2Entries * 64; i += 64 * kP1Waves) smem[i] = p.tab[i];
+    __syncthreads();
+    if (run >= p.nruns) return;                  // wave-uniform; no barrier after this point
+    v2f* ex = smem + kT2Entries * 64 + wave * kP1WaveLds;
+    float* xring = reinterpret_cast<float*>(ex + kScratch);
+    float* acc = xring + kP1Ring;
+    const v2f* tabl = smem + l;
+
+    const int H = p.H, T = p.T;
+    const int f0 = run * p.G;
+    const int f1 = min(f0 + p.G, T);
+    const int ovl = kN1 - H;
+    const int a3 = l & 7, g3 = l >> 3;
+    const int kloB = l ? 128 - l : 64;
+    const bool l0 = (l == 0);
+    const int g_h = p.G * H;
+    const float* xr = p.x_in + (long long)b * p.L;
+    const float* tr = p.tail_in ? p.tail_in + (long long)b * p.nruns * ovl : nullptr;
+
+#pragma unroll
+    for (int i = 0; i < kP1Ring / 64; ++i) acc[l + 64 * i] = 0.0f;
+
+    // magnitude index of the lane's 9 units: min(k, 1024-k)
+    int kk[9];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        int k = l ? (l + 128 * u) : (u < 4 ? 128 * u : 64 + 128 * (u - 4));
+        kk[u] = k <= 512 ? k : 1024 - k;
+    }
+    kk[8] = 512;
+
+    long long filled = (long long)f0 * H;        // x ring holds [.., filled)
+    for (int n = f0; n < f1; n += 2) {
+        const bool two = (n + 1 < f1);
+        const long long sn = (long long)n * H;
+        const long long need = sn + kN1 + (two ? H : 0);
+        for (long long s = filled + l; s < need; s += 64)
+            xring[(int)(s & (kP1Ring - 1))] = fetch_x(xr, tr, s, g_h, p.nruns, ovl);
+        filled = need;
+
+        float ma[9], mb[9];
+        {
+            const float* ra = p.mag + ((long long)b * T + n) * (kN1 / 2 + 1);
+            const float* rb = ra + (two ? (kN1 / 2 + 1) : 0);
+#pragma unroll
+            for (int u = 0; u < 9; ++u) { ma[u] = ra[kk[u]]; mb[u] = two ? rb[kk[u]] : 0.0f; }
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        v2f z[16];
+        bool a_nz = false, b_nz = false;
+        {
+            const int base_a = (int)(sn & (kP1Ring - 1));
+            const int base_b = (int)((sn + H) & (kP1Ring - 1));
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                float xa = xring[(base_a + l + 64 * j) & (kP1Ring - 1)];
+                float xb = two ? xring[(base_b + l + 64 * j) & (kP1Ring - 1)] : 0.0f;
+                a_nz |= (xa != 0.0f);
+                b_nz |= (xb != 0.0f);
+                v2f w = tabl[(kT2Win + j) * 64];
+                z[j].x = xa * w.x;
+                z[j].y = xb * w.y;
+            }
+        }
+        // an all-zero input frame must give an exactly zero spectrum (phase 0 after projection,
+        // audio_utilities.py:181): its partner's rounding noise must not set its phase
+        const float ka = __any(a_nz) ? 1.0f : 0.0f;
+        const float kb = __any(b_nz) ? 1.0f : 0.0f;
+
+        fft_forward_1024(z, ex, l, a3, g3, kloB, tabl);
+        middle_two_frames(z, l0, ma, mb, ka, kb);
+        fft_inverse_1024(z, ex, l, a3, g3, kloB, tabl);
+
+        // window, 1/1024, overlap-add: frame a then frame b (frame order, like the reference)
+        {
+            const int base_a = (int)(sn & (kP1Ring - 1));
+            const int base_b = (int)((sn + H) & (kP1Ring - 1));
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                v2f w = tabl[(kT2WinSc + j) * 64];
+                acc[(base_a + l + 64 * j) & (kP1Ring - 1)] += z[j].x * w.x;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (two) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    v2f w = tabl[(kT2WinSc + j) * 64];
+                    acc[(base_b + l + 64 * j) & (kP1Ring - 1)] += z[j].y * w.y;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // samples [sn, sn + H) (or 2H) are complete: emit once and clear
+            const int done = two ? 2 * H : H;
+            float* orow = p.x_out + (long long)b * p.L;
+            for (int i = l; i < done; i += 64) {
+                int q = (int)((sn + i) & (kP1Ring - 1));
+                orow[sn + i] = acc[q];
+                acc[q] = 0.0f;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+
+    // partial sums of the N-H samples after the run's last frame
+    const long long se = (long long)f1 * H;
+    if (f1 == T) {
+        float* orow = p.x_out + (long long)b * p.L;
+        for (int i = l; i < ovl; i += 64) orow[se + i] = acc[(int)((se + i) & (kP1Ring - 1))];
+        for (int i = l; i < H; i += 64) orow[se + ovl + i] = 0.0f;
+    } else {
+        float* trow = p.tail_out + ((long long)b * p.nruns + run) * ovl;
+        for (int i = l; i < ovl; i += 64) trow[i] = acc[(int)((se + i) & (kP1Ring - 1))];
+    }
+}
+
 // x_out[s] = x_main[s] + tail of the previous run (final fold after the last iteration)
 __global__ void __launch_bounds__(256) k_fold_tails(const float* __restrict__ x_main, const float* __restrict__ tail,
                                                     float* __restrict__ x_out, long long L, int g_h, int nruns,
@@ -724,9 +916,10 @@ int pick_run_length(const gl_plan* p, int B, int T, int waves_per_cu) {
     const int N = p->n_fft, H = p->hop;
     int g_min = (N - H + H - 1) / H;
     if (g_min < 1) g_min = 1;
-    if (const char* e = getenv("GL_RUN_FRAMES")) {
-        int G = atoi(e);
-        if (G < g_min) G = g_min;
+    int pinned = p->run_frames;
+    if (const char* e = getenv("GL_RUN_FRAMES")) pinned = atoi(e);   // experiments
+    if (pinned > 0) {
+        int G = pinned < g_min ? g_min : pinned;
         return G > T ? T : G;
     }
     if (T <= g_min) return T;
@@ -826,9 +1019,12 @@ int ensure_table2(gl_plan* p) {
     auto Wim = [&](int n, long long k) { return sin(-2.0 * pi * (double)(k % n) / (double)n); };
     for (int l = 0; l < 64; ++l) {
         for (int j = 0; j < 16; ++j) {
-            int n0 = 2 * (l + 64 * j);
+            // n_fft 2048: lane holds the even/odd sample pair 2(l+64j), +1 of ONE frame;
+            // n_fft 1024: lane holds sample l+64j of TWO frames (same window value twice)
+            int n0 = (N == kN) ? 2 * (l + 64 * j) : (l + 64 * j);
+            int n1 = (N == kN) ? n0 + 1 : n0;
             float w0 = (float)(0.5 - 0.5 * cos(2.0 * pi * n0 / (double)(N - 1)));
-            float w1 = (float)(0.5 - 0.5 * cos(2.0 * pi * (n0 + 1) / (double)(N - 1)));
+            float w1 = (float)(0.5 - 0.5 * cos(2.0 * pi * n1 / (double)(N - 1)));
             put(kT2Win + j, l, w0, w1);
             put(kT2WinSc + j, l, (double)w0 / kM, (double)w1 / kM);   // exact: power-of-two scale
         }
@@ -901,9 +1097,51 @@ int run_regring(gl_plan* p, const float* mag, const float* x0, float* x_out, int
     return 0;
 }
 
+
+int run_pair1024(gl_plan* p, const float* mag, const float* x0, float* x_out, int iters, int B, int T,
+                 hipStream_t st) {
+    int rc = ensure_table2(p);
+    if (!rc) rc = ensure_buffers(p);
+    if (rc) return rc;
+    const int G = pick_run_length(p, B, T, kP1Waves);
+    const int nruns = (T + G - 1) / G;
+    Pair1024Args a = {};
+    a.mag = mag;
+    a.tab = reinterpret_cast<const v2f*>(p->d_fast_tab2);
+    a.H = p->hop;
+    a.T = T;
+    a.G = G;
+    a.nruns = nruns;
+    a.L = gl_len(p->n_fft, p->hop, T);
+    dim3 grid((nruns + kP1Waves - 1) / kP1Waves, B);
+    const float* src = x0;
+    const float* src_tail = nullptr;
+    for (int it = 0; it < iters; ++it) {
+        const bool last = (it == iters - 1);
+        float* dst = (it & 1) ? p->d_xb : p->d_xa;
+        float* dst_tail = (it & 1) ? p->d_tail_b : p->d_tail_a;
+        if (last && nruns == 1) dst = x_out;
+        a.x_in = src;
+        a.tail_in = src_tail;
+        a.x_out = dst;
+        a.tail_out = dst_tail;
+        hipLaunchKernelGGL(k_gl1024_pair, grid, dim3(64 * kP1Waves), 0, st, a);
+        GL_HIP_CHECK(hipGetLastError());
+        src = dst;
+        src_tail = (nruns > 1) ? dst_tail : nullptr;
+    }
+    if (nruns > 1) return fold(p, src, src_tail, x_out, B, T, G, nruns, st);
+    return 0;
+}
+
 }  // namespace
 
-bool gl_fast_supported(const gl_plan* p) { return p->n_fft == kN && p->hop <= kN && p->hop >= 1; }
+bool gl_fast_supported(const gl_plan* p, int op) {
+    if (p->hop < 1) return false;
+    if (p->n_fft == kN && p->hop <= kN) return true;                          // all three entry points
+    if (p->n_fft == kN1 && p->hop <= kN1) return op == GL_FAST_OP_RUN;         // Griffin-Lim loop only
+    return false;
+}
 
 int gl_fast_stft(gl_plan* p, const float* x, long long x_stride, float* S, int B, int T, hipStream_t st) {
     int rc = ensure_table(p);
@@ -942,6 +1180,7 @@ int gl_fast_istft(gl_plan* p, const float* S, float* y, int B, int T, hipStream_
 
 int gl_fast_run(gl_plan* p, const float* mag, const float* x0, float* x_out, int iters, int B, int T,
                 hipStream_t st) {
+    if (p->n_fft == kN1) return run_pair1024(p, mag, x0, x_out, iters, B, T, st);
     if (p->path == 0 && regring_ok(p, x0, x_out)) return run_regring(p, mag, x0, x_out, iters, B, T, st);
     int rc = ensure_table(p);
     if (!rc) rc = ensure_buffers(p);

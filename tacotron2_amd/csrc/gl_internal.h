@@ -13,6 +13,7 @@ struct gl_plan {
     int max_B;
     int device;
     int path;         // 0 auto, 1 generic
+    int run_frames;   // frames per wave-run of the fused kernels; 0 = choose from (B, T)
     int n_cu;         // compute units of the device
     float* d_window;  // [N]   symmetric Hann
     float2* d_tw;     // [N]   exp(-2*pi*i*k/N)
@@ -48,7 +49,8 @@ int gl_generic_run(gl_plan* p, const float* mag, const float* x0, float* x_out, 
                    hipStream_t st);
 
 // ---- fused wave-per-frame kernels: gl_fast.hip -----------------------------------
-bool gl_fast_supported(const gl_plan* p);
+enum { GL_FAST_OP_STFT = 0, GL_FAST_OP_ISTFT = 1, GL_FAST_OP_RUN = 2 };
+bool gl_fast_supported(const gl_plan* p, int op);
 int gl_fast_stft(gl_plan* p, const float* x, long long x_stride, float* S, int B, int T, hipStream_t st);
 int gl_fast_istft(gl_plan* p, const float* S, float* y, int B, int T, hipStream_t st);
 int gl_fast_run(gl_plan* p, const float* mag, const float* x0, float* x_out, int iters, int B, int T,

@@ -65,6 +65,11 @@ class Plan:
         """0 = auto (fused kernels where available), 1 = force the generic kernels."""
         _lib.check(self._lib.gl_plan_set_path(self._h, int(path)), "gl_plan_set_path")
 
+    def set_run_frames(self, frames):
+        """Pin the frames-per-wave-run of the fused kernels (0 = automatic).  Pin it when results
+        for different batch sizes (per-GPU shards vs one batch) must be bit-identical."""
+        _lib.check(self._lib.gl_plan_set_run_frames(self._h, int(frames)), "gl_plan_set_run_frames")
+
     def _f32(self, t, shape=None):
         if t.device != self.device or t.dtype != torch.float32 or not t.is_contiguous():
             raise ValueError("expected a contiguous float32 tensor on %s" % (self.device,))

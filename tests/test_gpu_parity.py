@@ -297,3 +297,49 @@ def test_ill_conditioned_input_tracks_oracle_while_conditioning_allows():
         got = p.run(mag, x0, K)[0].cpu().numpy()
         ref = orc.griffin_lim_vec(mag0, N, H, K, x0[0].cpu().numpy().astype(np.float64))
         assert peak_err(got, ref) <= TOL_GL, K
+
+
+def test_n1024_all_zero_frame_next_to_live_frame():
+    """The n_fft-1024 kernel packs two real frames into one complex FFT.  An all-zero input
+    frame must still come out with phase 0 (np.angle(0) == 0, audio_utilities.py:181) even when
+    its partner frame is not zero."""
+    N, H, T = 1024, 275, 9
+    rng = np.random.default_rng(11)
+    mag = np.abs(rng.standard_normal((T, N // 2 + 1))).astype(np.float32)
+    for zero_to in (N, N + H, N + 2 * H):          # frame 0 / frames 0-1 / frames 0-2 see only zeros
+        x0 = rng.standard_normal(T * H + N).astype(np.float32)
+        x0[:zero_to] = 0.0
+        ref = orc.griffin_lim_vec(mag.astype(np.float64), N, H, 2, x0.astype(np.float64))
+        for path in PATHS:
+            p = _plan(N, H, T, 1, path)
+            y = p.run(torch.from_numpy(mag).cuda()[None], torch.from_numpy(x0).cuda()[None], 2)[0].cpu().numpy()
+            assert peak_err(y, ref) <= TOL_GL, (zero_to, path, peak_err(y, ref))
+            p.close()
+
+
+def test_config5_geometry_batch32():
+    """BASELINE config 5 geometry: batch 32, T = 1001 decoder frames (model.py:326), params.py
+    defaults n_fft 1024 / hop 275, 60 iterations: two utterances against the oracle, batch rows
+    bit-identical to single runs."""
+    N, H, T, B, K = 1024, 275, 1001, 32, 60
+    from bench import synth_mels
+    mel = torch.from_numpy(synth_mels(B, T, 77)).cuda()
+    fb = torch.from_numpy(filters.mel(22050, N, 80, 125, 7600)).cuda()
+    p = get_plan(N, H, T, B)
+    mag = p.mel_to_mag(fb, mel)
+    x0 = torch.from_numpy(np.random.default_rng(5).standard_normal((B, T * H + N)).astype(np.float32)).cuda()
+    y = p.run(mag, x0, K)
+    assert torch.isfinite(y).all() and torch.all(y[:, -H:] == 0)
+    # automatic run length depends on the batch size: rows agree to rounding ...
+    y7 = p.run(mag[7:8].contiguous(), x0[7:8].contiguous(), K)
+    assert peak_err(y7[0].cpu().numpy(), y[7].cpu().numpy()) <= 1e-4
+    # ... and bit for bit once the run length is pinned (what a sharded multi-GPU job does)
+    p.set_run_frames(32)
+    yp = p.run(mag, x0, K)
+    y7 = p.run(mag[7:8].contiguous(), x0[7:8].contiguous(), K)
+    assert torch.equal(y7[0], yp[7])
+    p.set_run_frames(0)
+    for i in (0, 31):
+        mi = mag[i].cpu().numpy().astype(np.float64)
+        ref = orc.griffin_lim_vec(mi, N, H, K, x0[i].cpu().numpy().astype(np.float64))
+        assert peak_err(y[i].cpu().numpy(), ref) <= TOL_GL

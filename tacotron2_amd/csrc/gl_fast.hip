@@ -54,18 +54,8 @@ constexpr int kTabEntries = 94;
 enum { MODE_GL = 0, MODE_STFT = 1, MODE_ISTFT = 2 };
 
 // ---- complex helpers on v2f --------------------------------------------------------------
-__device__ __forceinline__ v2f cmul(v2f a, v2f w) {
-    v2f r;
-    r.x = a.x * w.x - a.y * w.y;
-    r.y = a.x * w.y + a.y * w.x;
-    return r;
-}
-__device__ __forceinline__ v2f cmulc(v2f a, v2f w) {  // a * conj(w)
-    v2f r;
-    r.x = a.x * w.x + a.y * w.y;
-    r.y = a.y * w.x - a.x * w.y;
-    return r;
-}
+#include "gl_pk.h"   // cmul, cmulc, cmul_add, ... and the one-instruction packed forms
+
 template <bool INV>
 __device__ __forceinline__ v2f ctw(v2f a, v2f w) { return INV ? cmulc(a, w) : cmul(a, w); }
 __device__ __forceinline__ v2f mul_mi(v2f a) { v2f r; r.x = a.y; r.y = -a.x; return r; }   // -i*a
@@ -76,77 +66,80 @@ __device__ __forceinline__ v2f cconj(v2f a) { v2f r; r.x = a.x; r.y = -a.y; retu
 // (dynamic register indexing); passing by value keeps it a v_cndmask on data
 __device__ __forceinline__ v2f sel(bool c, v2f a, v2f b) { v2f r; r.x = c ? a.x : b.x; r.y = c ? a.y : b.y; return r; }
 
+// The DFT kernels below are written in packed operations: with r = W4 = -i (forward) or +i
+// (inverse), a + r*b and a - r*b are one v_pk_add each, a multiplication by W8 = (1 + r)/sqrt 2
+// is one v_pk_add (a + r*a) whose 1/sqrt 2 rides the next butterfly as a v_pk_fma.
+template <bool INV> __device__ __forceinline__ v2f add_r(v2f a, v2f b) { return INV ? pk_addi(a, b) : pk_subi(a, b); }
+template <bool INV> __device__ __forceinline__ v2f sub_r(v2f a, v2f b) { return INV ? pk_subi(a, b) : pk_addi(a, b); }
+__device__ __forceinline__ v2f fma_s(v2f a, float s, v2f c) { return __builtin_elementwise_fma(a, (v2f){s, s}, c); }  // c + s*a
+// a * (wx + i*wy) for a compile-time twiddle (conjugated when INV)
+template <bool INV>
+__device__ __forceinline__ v2f cmul_k(v2f a, float wx, float wy) {
+    const float y = INV ? -wy : wy;
+    return __builtin_elementwise_fma(a.yy, (v2f){-y, wx}, a.xx * (v2f){wx, y});
+}
+
+constexpr float kH = 0.70710678118654752440f;   // 1/sqrt 2
+
 template <bool INV>
 __device__ __forceinline__ void dft4(v2f& a0, v2f& a1, v2f& a2, v2f& a3) {
     v2f s0 = a0 + a2, s1 = a0 - a2, s2 = a1 + a3, s3 = a1 - a3;
-    v2f t = INV ? mul_pi(s3) : mul_mi(s3);
     a0 = s0 + s2;
     a2 = s0 - s2;
-    a1 = s1 + t;
-    a3 = s1 - t;
+    a1 = add_r<INV>(s1, s3);
+    a3 = sub_r<INV>(s1, s3);
 }
 
-// multiply by W8^1 / W8^3 (forward: exp(-i*pi/4), exp(-3i*pi/4); inverse: conjugates)
-template <bool INV>
-__device__ __forceinline__ v2f mul_w8_1(v2f a) {
-    const float h = 0.70710678118654752440f;
-    v2f r;
-    if (!INV) { r.x = (a.x + a.y) * h; r.y = (a.y - a.x) * h; }
-    else      { r.x = (a.x - a.y) * h; r.y = (a.x + a.y) * h; }
-    return r;
-}
-template <bool INV>
-__device__ __forceinline__ v2f mul_w8_3(v2f a) {
-    const float h = 0.70710678118654752440f;
-    v2f r;
-    if (!INV) { r.x = (a.y - a.x) * h; r.y = -(a.x + a.y) * h; }
-    else      { r.x = -(a.x + a.y) * h; r.y = (a.x - a.y) * h; }
-    return r;
-}
-
-// natural-order in-place DFT-8 on v[0..7]
+// natural-order in-place DFT-8 on v[0..7]  (26 packed operations)
 template <bool INV>
 __device__ __forceinline__ void dft8(v2f* v) {
     dft4<INV>(v[0], v[2], v[4], v[6]);   // E0..E3 in v0,v2,v4,v6
     dft4<INV>(v[1], v[3], v[5], v[7]);   // O0..O3 in v1,v3,v5,v7
-    v2f o1 = mul_w8_1<INV>(v[3]);
-    v2f o2 = INV ? mul_pi(v[5]) : mul_mi(v[5]);
-    v2f o3 = mul_w8_3<INV>(v[7]);
-    v2f e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1];
-    v[0] = e0 + o0; v[4] = e0 - o0;
-    v[1] = e1 + o1; v[5] = e1 - o1;
-    v[2] = e2 + o2; v[6] = e2 - o2;
-    v[3] = e3 + o3; v[7] = e3 - o3;
+    const v2f e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1], o2 = v[5];
+    const v2f t1 = add_r<INV>(v[3], v[3]);   // O1 * W8^1 =  h * t1
+    const v2f t3 = sub_r<INV>(v[7], v[7]);   // O3 * W8^3 = -h * t3
+    v[0] = e0 + o0;             v[4] = e0 - o0;
+    v[1] = fma_s(t1, kH, e1);   v[5] = fma_s(t1, -kH, e1);
+    v[2] = add_r<INV>(e2, o2);  v[6] = sub_r<INV>(e2, o2);
+    v[3] = fma_s(t3, -kH, e3);  v[7] = fma_s(t3, kH, e3);
 }
 
-// natural-order in-place DFT-16 on v[0..15]
+// natural-order in-place DFT-16 on v[0..15]  (78 packed operations)
 template <bool INV>
 __device__ __forceinline__ void dft16(v2f* v) {
-    const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f;  // cos, sin(pi/8)
-    // step 1: for r = 0..3, DFT4 over m of x[r + 4m] -> E_r[q] kept in v[r + 4q]
+    constexpr float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f;  // cos, sin(pi/8)
+    // step 1: for rho = 0..3, DFT4 over m of x[rho + 4m] -> E_rho[q] kept in v[rho + 4q]
 #pragma unroll
     for (int r = 0; r < 4; ++r) dft4<INV>(v[r], v[r + 4], v[r + 8], v[r + 12]);
-    // step 2: twiddle E_r[q] *= W16^(r*q)
-    const v2f w1 = {c1, -s1}, w3 = {s1, -c1};     // W16^1, W16^3 (forward)
-    v[5] = ctw<INV>(v[5], w1);                    // r=1,q=1
-    v[9] = mul_w8_1<INV>(v[9]);                   // r=1,q=2 : W16^2
-    v[13] = ctw<INV>(v[13], w3);                  // r=1,q=3
-    v[6] = mul_w8_1<INV>(v[6]);                   // r=2,q=1 : W16^2
-    v[10] = INV ? mul_pi(v[10]) : mul_mi(v[10]);  // r=2,q=2 : W16^4
-    v[14] = mul_w8_3<INV>(v[14]);                 // r=2,q=3 : W16^6
-    v[7] = ctw<INV>(v[7], w3);                    // r=3,q=1
-    v[11] = mul_w8_3<INV>(v[11]);                 // r=3,q=2 : W16^6
-    {                                             // r=3,q=3 : W16^9 = -W16^1
-        v2f t = ctw<INV>(v[15], w1);
-        v[15] = -t;
-    }
-    // step 3: for q = 0..3, DFT4 over r of v[r + 4q] -> X[q + 4p] ; then reorder
+    // steps 2+3: for q = 0..3, DFT4 over rho of E_rho[q] * W16^(rho*q) -> X[q + 4p]
     v2f out[16];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        v2f a0 = v[4 * q], a1 = v[4 * q + 1], a2 = v[4 * q + 2], a3 = v[4 * q + 3];
+    {   // q = 0
+        v2f a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
         dft4<INV>(a0, a1, a2, a3);
-        out[q] = a0; out[q + 4] = a1; out[q + 8] = a2; out[q + 12] = a3;
+        out[0] = a0; out[4] = a1; out[8] = a2; out[12] = a3;
+    }
+    {   // q = 1: twiddles 1, W16^1, W8^1, W16^3
+        const v2f a1 = cmul_k<INV>(v[5], c1, -s1), a3 = cmul_k<INV>(v[7], s1, -c1);
+        const v2f t2 = add_r<INV>(v[6], v[6]);                     // v6 * W8^1 = h * t2
+        const v2f s0 = fma_s(t2, kH, v[4]), s1_ = fma_s(t2, -kH, v[4]);
+        const v2f s2 = a1 + a3, s3 = a1 - a3;
+        out[1] = s0 + s2; out[9] = s0 - s2; out[5] = add_r<INV>(s1_, s3); out[13] = sub_r<INV>(s1_, s3);
+    }
+    {   // q = 2: twiddles 1, W8^1, r, W8^3
+        const v2f s0 = add_r<INV>(v[8], v[10]), s1_ = sub_r<INV>(v[8], v[10]);
+        const v2f t1 = add_r<INV>(v[9], v[9]), t1r = sub_r<INV>(v[9], v[9]);       // a1 = h*t1,  r*a1 = -h*t1r
+        const v2f t3 = sub_r<INV>(v[11], v[11]), t3r = add_r<INV>(v[11], v[11]);   // a3 = -h*t3, r*a3 = -h*t3r
+        const v2f u2 = t1 - t3;      // (a1 + a3) / h
+        const v2f u3 = t3r - t1r;    // r * (a1 - a3) / h
+        out[2] = fma_s(u2, kH, s0);  out[10] = fma_s(u2, -kH, s0);
+        out[6] = fma_s(u3, kH, s1_); out[14] = fma_s(u3, -kH, s1_);
+    }
+    {   // q = 3: twiddles 1, W16^3, W8^3, W16^9 = -W16^1
+        const v2f a1 = cmul_k<INV>(v[13], s1, -c1), a3 = cmul_k<INV>(v[15], -c1, s1);
+        const v2f t2 = sub_r<INV>(v[14], v[14]);                   // v14 * W8^3 = -h * t2
+        const v2f s0 = fma_s(t2, -kH, v[12]), s1_ = fma_s(t2, kH, v[12]);
+        const v2f s2 = a1 + a3, s3 = a1 - a3;
+        out[3] = s0 + s2; out[11] = s0 - s2; out[7] = add_r<INV>(s1_, s3); out[15] = sub_r<INV>(s1_, s3);
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] = out[i];
@@ -450,7 +443,7 @@ constexpr int kT2Win = 0;       // 16: (w[2(l+64j)], w[2(l+64j)+1])
 constexpr int kT2WinSc = 16;    // 16: the same / 1024
 constexpr int kT2Tw1 = 32;      // 15: W1024^(l*k2), k2 = 1..15
 constexpr int kT2Tw2 = 47;      // 7:  W64^(a*d), d = 1..7
-constexpr int kT2Twp = 54;      // 9:  W2048^(kP[u])
+constexpr int kT2Twp = 54;      // 9:  -i * W2048^(kP[u])
 constexpr int kT2Entries = 63;
 
 __device__ __forceinline__ void fft_forward_1024(v2f* z, v2f* ex, int l, int a3, int g3, int kloB,
@@ -543,12 +536,16 @@ __device__ __forceinline__ void middle_project(v2f* z, bool l0, const float* m_l
     Q[8] = z[4];
 #pragma unroll
     for (int u = 0; u < 9; ++u) {
-        v2f w = tabl[(kT2Twp + u) * 64];
-        v2f Xk, Xmk;
-        pair_fwd(P[u], Q[u], w, Xk, Xmk);
-        Xk = project(Xk, m_lo[u]);
-        Xmk = project(Xmk, m_hi[u]);
-        pair_inv(Xk, Xmk, w, P[u], Q[u]);
+        // w = -i*W2048^k.  2X[k] = (P + conj Q) + w*(P - conj Q), 2conj(X[M-k]) = the same with -w;
+        // the projection is scale-free and commutes with conj; back: 2z[k] = (X+Y) + (X-Y)*conj(w),
+        // 2z[M-k] = conj((X+Y) - (X-Y)*conj(w)).  The factor 2 is folded into the scaled window.
+        const v2f w = tabl[(kT2Twp + u) * 64];
+        const v2f uu = pk_addc(P[u], Q[u]), vv = pk_subc(P[u], Q[u]);
+        const v2f X = project(cmul_add(vv, w, uu), m_lo[u]);
+        const v2f Y = project(cmul_sub(vv, w, uu), m_hi[u]);
+        const v2f a2 = X + Y, b2 = X - Y;
+        P[u] = cmulc_add(b2, w, a2);
+        Q[u] = cmulc_subconj(b2, w, a2);
     }
     z[0] = P[0];
 #pragma unroll
@@ -1026,13 +1023,15 @@ int ensure_table2(gl_plan* p) {
             float w0 = (float)(0.5 - 0.5 * cos(2.0 * pi * n0 / (double)(N - 1)));
             float w1 = (float)(0.5 - 0.5 * cos(2.0 * pi * n1 / (double)(N - 1)));
             put(kT2Win + j, l, w0, w1);
-            put(kT2WinSc + j, l, (double)w0 / kM, (double)w1 / kM);   // exact: power-of-two scale
+            // 1/M of the inverse transform; the 2048 kernel's split step leaves another factor 2
+            const double sc = (N == kN) ? 2.0 * kM : (double)kM;
+            put(kT2WinSc + j, l, (double)w0 / sc, (double)w1 / sc);   // exact: power-of-two scale
         }
         for (int k2 = 1; k2 < 16; ++k2) put(kT2Tw1 + k2 - 1, l, Wre(1024, (long long)l * k2), Wim(1024, (long long)l * k2));
         for (int d = 1; d < 8; ++d) put(kT2Tw2 + d - 1, l, Wre(64, (long long)(l & 7) * d), Wim(64, (long long)(l & 7) * d));
         for (int u = 0; u < 9; ++u) {
             int k = (u == 8) ? 512 : (l ? l + 128 * u : (u < 4 ? 128 * u : 64 + 128 * (u - 4)));
-            put(kT2Twp + u, l, Wre(2048, k), Wim(2048, k));
+            put(kT2Twp + u, l, Wim(2048, k), -Wre(2048, k));   // -i * W2048^k (middle_project)
         }
     }
     int rc = gl_plan_alloc(p, (void**)&p->d_fast_tab2, tab.size() * sizeof(float));

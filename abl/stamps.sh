@@ -1,0 +1,2 @@
+#!/bin/bash
+GL_HIP_LIB=/root/repo/abl/libgl_ablstamps.so timeout -k 10 120 python bench.py --cpu-seconds 0 --steps 1 --warmup 0 2>&1 | grep -v amdgpu.ids | cut -c1-200

@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgl_hip.so")
+LIB_PATH = os.environ.get("GL_HIP_LIB") or os.path.join(_HERE, "libgl_hip.so")   # override: kernel experiments
 
 _c_float_p = ctypes.c_void_p   # device pointers travel as integers
 _plan_p = ctypes.c_void_p

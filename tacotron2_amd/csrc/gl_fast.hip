@@ -27,6 +27,7 @@
 // :112-113 (irfft, window, overlap-add) per iteration of :178-187.
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <vector>
 
@@ -55,6 +56,16 @@ enum { MODE_GL = 0, MODE_STFT = 1, MODE_ISTFT = 2 };
 
 // ---- complex helpers on v2f --------------------------------------------------------------
 #include "gl_pk.h"   // cmul, cmulc, cmul_add, ... and the one-instruction packed forms
+
+// LDS read.  -DGL_LDS_VOLATILE keeps the optimiser from pairing reads into ds_read2_b64 /
+// ds_read2st64_b64 (half the rate of two ds_read_b64 per MI355X_MICROARCH.md); measured 4 % SLOWER
+// on config 2 (0.185 vs 0.178 ms) because volatile also pins the reads' order, so it is off.
+#ifdef GL_LDS_VOLATILE
+typedef const volatile __attribute__((address_space(3))) v2f* lds_cvp;
+__device__ __forceinline__ v2f lds_rd(const v2f* q) { return *(lds_cvp)q; }
+#else
+__device__ __forceinline__ v2f lds_rd(const v2f* q) { return *q; }
+#endif
 
 template <bool INV>
 __device__ __forceinline__ v2f ctw(v2f a, v2f w) { return INV ? cmulc(a, w) : cmul(a, w); }
@@ -444,13 +455,54 @@ constexpr int kT2WinSc = 16;    // 16: the same / 1024
 constexpr int kT2Tw1 = 32;      // 15: W1024^(l*k2), k2 = 1..15
 constexpr int kT2Tw2 = 47;      // 7:  W64^(a*d), d = 1..7
 constexpr int kT2Twp = 54;      // 9:  -i * W2048^(kP[u])
-constexpr int kT2Entries = 63;
+constexpr int kT2Entries = 63;   // entries copied to LDS
+constexpr int kT2Zero = 63;      // global-only: one row of zeros (the "no tail" operand of load_row)
+
+// Phase timing for kernel studies (-DGL_STAMPS): every phase boundary drains the LDS queue and
+// reads the shader clock; lane 0 of every wave adds its per-phase totals to g_stamp at exit.
+// The drain serialises what the normal build overlaps, so the sum exceeds the normal run time.
+#ifdef GL_STAMPS
+__device__ unsigned long long g_stamp[24];
+struct Stamps {
+    unsigned long long prev;
+    unsigned acc[20];
+    __device__ __forceinline__ void start() {
+#pragma unroll
+        for (int i = 0; i < 20; ++i) acc[i] = 0;
+        prev = now();
+    }
+    __device__ __forceinline__ static unsigned long long now() {
+        unsigned long long t;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+        return t;
+    }
+    __device__ __forceinline__ void mark(int i) {
+        unsigned long long t = now();
+        acc[i] += (unsigned)(t - prev);
+        prev = t;
+    }
+    __device__ __forceinline__ void flush(int lane) {
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 20; ++i) atomicAdd(&g_stamp[i], (unsigned long long)acc[i]);
+            atomicAdd(&g_stamp[20], 1ull);
+        }
+    }
+};
+#else
+struct Stamps {
+    __device__ __forceinline__ void start() {}
+    __device__ __forceinline__ void mark(int) {}
+    __device__ __forceinline__ void flush(int) {}
+};
+#endif
 
 __device__ __forceinline__ void fft_forward_1024(v2f* z, v2f* ex, int l, int a3, int g3, int kloB,
-                                                 const v2f* __restrict__ tabl) {
+                                                 const v2f* __restrict__ tabl, Stamps& st) {
     dft16<false>(z);
 #pragma unroll
-    for (int k2 = 1; k2 < 16; ++k2) z[k2] = cmul(z[k2], tabl[(kT2Tw1 + k2 - 1) * 64]);
+    for (int k2 = 1; k2 < 16; ++k2) z[k2] = cmul(z[k2], (GL_ABL & 4) ? (v2f){0.6f, 0.8f} : lds_rd(&tabl[(kT2Tw1 + k2 - 1) * 64]));
+    st.mark(1);
     if (!(GL_ABL & 1)) {
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -459,16 +511,18 @@ __device__ __forceinline__ void fft_forward_1024(v2f* z, v2f* ex, int l, int a3,
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int bb = 0; bb < 8; ++bb) z[8 * h + bb] = ex[(g3 + 8 * h) * kEx1Stride + a3 + 8 * bb];
+        for (int bb = 0; bb < 8; ++bb) z[8 * h + bb] = lds_rd(&ex[(g3 + 8 * h) * kEx1Stride + a3 + 8 * bb]);
     }
+    st.mark(2);
     dft8<false>(z);
     dft8<false>(z + 8);
 #pragma unroll
     for (int d = 1; d < 8; ++d) {
-        v2f w = tabl[(kT2Tw2 + d - 1) * 64];
+        v2f w = (GL_ABL & 4) ? (v2f){0.6f, 0.8f} : lds_rd(&tabl[(kT2Tw2 + d - 1) * 64]);
         z[d] = cmul(z[d], w);
         z[8 + d] = cmul(z[8 + d], w);
     }
+    st.mark(3);
     if (!(GL_ABL & 1)) {
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -477,16 +531,19 @@ __device__ __forceinline__ void fft_forward_1024(v2f* z, v2f* ex, int l, int a3,
         for (int d = 0; d < 8; ++d) ex[a3 * kEx2Stride + 16 * d + g3 + 8 * h] = z[8 * h + d];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int a = 0; a < 8; ++a) { z[a] = ex[a * kEx2Stride + l]; z[8 + a] = ex[a * kEx2Stride + kloB]; }
+    for (int a = 0; a < 8; ++a) { z[a] = lds_rd(&ex[a * kEx2Stride + l]); z[8 + a] = lds_rd(&ex[a * kEx2Stride + kloB]); }
     }
+    st.mark(4);
     dft8<false>(z);
     dft8<false>(z + 8);
+    st.mark(5);
 }
 
 __device__ __forceinline__ void fft_inverse_1024(v2f* z, v2f* ex, int l, int a3, int g3, int kloB,
-                                                 const v2f* __restrict__ tabl) {
+                                                 const v2f* __restrict__ tabl, Stamps& st) {
     dft8<true>(z);
     dft8<true>(z + 8);
+    st.mark(7);
     if (!(GL_ABL & 1)) {
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -495,16 +552,18 @@ __device__ __forceinline__ void fft_inverse_1024(v2f* z, v2f* ex, int l, int a3,
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int d = 0; d < 8; ++d) z[8 * h + d] = ex[a3 * kEx2StrideInv + 16 * d + g3 + 8 * h];
+        for (int d = 0; d < 8; ++d) z[8 * h + d] = lds_rd(&ex[a3 * kEx2StrideInv + 16 * d + g3 + 8 * h]);
     }
+    st.mark(8);
 #pragma unroll
     for (int d = 1; d < 8; ++d) {
-        v2f w = tabl[(kT2Tw2 + d - 1) * 64];
+        v2f w = (GL_ABL & 4) ? (v2f){0.6f, 0.8f} : lds_rd(&tabl[(kT2Tw2 + d - 1) * 64]);
         z[d] = cmulc(z[d], w);
         z[8 + d] = cmulc(z[8 + d], w);
     }
     dft8<true>(z);
     dft8<true>(z + 8);
+    st.mark(9);
     if (!(GL_ABL & 1)) {
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -513,11 +572,13 @@ __device__ __forceinline__ void fft_inverse_1024(v2f* z, v2f* ex, int l, int a3,
         for (int bb = 0; bb < 8; ++bb) ex[(g3 + 8 * h) * kEx1Stride + a3 + 8 * bb] = z[8 * h + bb];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int k2 = 0; k2 < 16; ++k2) z[k2] = ex[k2 * kEx1Stride + l];
+    for (int k2 = 0; k2 < 16; ++k2) z[k2] = lds_rd(&ex[k2 * kEx1Stride + l]);
     }
+    st.mark(10);
 #pragma unroll
-    for (int k2 = 1; k2 < 16; ++k2) z[k2] = cmulc(z[k2], tabl[(kT2Tw1 + k2 - 1) * 64]);
+    for (int k2 = 1; k2 < 16; ++k2) z[k2] = cmulc(z[k2], (GL_ABL & 4) ? (v2f){0.6f, 0.8f} : lds_rd(&tabl[(kT2Tw1 + k2 - 1) * 64]));
     dft16<true>(z);
+    st.mark(11);
 }
 
 // rfft split + magnitude projection + inverse split on the 9 lane-local mirror pairs.
@@ -539,7 +600,7 @@ __device__ __forceinline__ void middle_project(v2f* z, bool l0, const float* m_l
         // w = -i*W2048^k.  2X[k] = (P + conj Q) + w*(P - conj Q), 2conj(X[M-k]) = the same with -w;
         // the projection is scale-free and commutes with conj; back: 2z[k] = (X+Y) + (X-Y)*conj(w),
         // 2z[M-k] = conj((X+Y) - (X-Y)*conj(w)).  The factor 2 is folded into the scaled window.
-        const v2f w = tabl[(kT2Twp + u) * 64];
+        const v2f w = lds_rd(&tabl[(kT2Twp + u) * 64]);
         const v2f uu = pk_addc(P[u], Q[u]), vv = pk_subc(P[u], Q[u]);
         const v2f X = project(cmul_add(vv, w, uu), m_lo[u]);
         const v2f Y = project(cmul_sub(vv, w, uu), m_hi[u]);
@@ -615,17 +676,24 @@ __global__ void __launch_bounds__(64 * kRRWaves, GL_RR_OCC) k_gl2048_regring(Ali
     const float* xrun = xr + (long long)f0 * H;
     const float* t_prev = tr ? tr + (long long)(run - own_prev) * ovl : nullptr;
     const float* t_own = tr ? tr + (long long)run * ovl : nullptr;
-    auto load_row = [&](int rel) -> v2f {
-        v2f v = *reinterpret_cast<const v2f*>(xrun + rel);
+    // Branch-free in the data: the tail operand comes from the tail buffers or from a row of
+    // zeros, chosen by wave-uniform pointer selects.  (Branches around the second load made the
+    // compiler wait for the first one at the join: a load round trip per row per frame.)
+    const float* zrow = reinterpret_cast<const float*>(p.tab + kT2Zero * 64) + 2 * l;
+    auto tail_ptr = [&](int rel) -> const float* {
+        const float* tp = zrow;
         if (has_tail) {
             const int rel_next = rel - gh;
             if (has_next && rel_next >= 0) {
-                if (rel_next < ovl) v += *reinterpret_cast<const v2f*>(t_own + rel_next);
+                if (rel_next < ovl) tp = t_own + rel_next;
             } else if (own_prev && rel < ovl) {
-                v += *reinterpret_cast<const v2f*>(t_prev + rel);
+                tp = t_prev + rel;
             }
         }
-        return v;
+        return tp;
+    };
+    auto load_row = [&](int rel) -> v2f {
+        return *reinterpret_cast<const v2f*>(xrun + rel) + *reinterpret_cast<const v2f*>(tail_ptr(rel));
     };
 
     v2f xraw[16], accr[16];
@@ -636,6 +704,13 @@ __global__ void __launch_bounds__(64 * kRRWaves, GL_RR_OCC) k_gl2048_regring(Ali
             accr[j] = (v2f){0.0f, 0.0f};
         }
     }
+    // Drain the ring-fill loads here.  Otherwise the loop header inherits "xraw[8..15] still in
+    // flight" from this prologue and the compiler guards every frame's window multiply with
+    // s_waitcnt vmcnt(24..17), which in steady state waits for the rows it has just requested
+    // for the NEXT frame: one exposed global-load round trip per frame.
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) only
+    Stamps st;
+    st.start();
 
     for (int n = f0; n < f1; ++n) {
         const long long sn = (long long)n * H;
@@ -643,12 +718,16 @@ __global__ void __launch_bounds__(64 * kRRWaves, GL_RR_OCC) k_gl2048_regring(Ali
 
         // prefetch the HS rows the next frame adds
         const bool more = (n + 1 < f1);
-        v2f xnew[HS];
+        // (both halves of each row are requested here and summed only at the end of the frame;
+        // past the run's last frame they come from the zero row: no branch around the loads)
+        v2f xnew[HS], xnew_t[HS];
 #pragma unroll
-        for (int jj = 0; jj < HS; ++jj) xnew[jj] = (v2f){0.0f, 0.0f};
-        if (more) {
-#pragma unroll
-            for (int jj = 0; jj < HS; ++jj) xnew[jj] = load_row((n - f0) * H + kN + 128 * jj);
+        for (int jj = 0; jj < HS; ++jj) {
+            const int rel = (n - f0) * H + kN + 128 * jj;
+            const float* xp = more ? xrun + rel : zrow;
+            const float* tp = more ? tail_ptr(rel) : zrow;
+            xnew[jj] = *reinterpret_cast<const v2f*>(xp);
+            xnew_t[jj] = *reinterpret_cast<const v2f*>(tp);
         }
         // this frame's magnitudes at the lane's 9 mirror pairs
         float m_lo[9], m_hi[9];
@@ -667,13 +746,15 @@ __global__ void __launch_bounds__(64 * kRRWaves, GL_RR_OCC) k_gl2048_regring(Ali
 
         v2f z[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) z[j] = xraw[j] * tabl[(kT2Win + j) * 64];
-        fft_forward_1024(z, ex, l, a3, g3, kloB, tabl);
+        for (int j = 0; j < 16; ++j) z[j] = xraw[j] * lds_rd(&tabl[(kT2Win + j) * 64]);
+        st.mark(0);
+        fft_forward_1024(z, ex, l, a3, g3, kloB, tabl, st);
         if (!(GL_ABL & 2)) middle_project(z, l0, m_lo, m_hi, tabl);
-        fft_inverse_1024(z, ex, l, a3, g3, kloB, tabl);
+        st.mark(6);
+        fft_inverse_1024(z, ex, l, a3, g3, kloB, tabl, st);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            v2f w = tabl[(kT2WinSc + j) * 64];
+            v2f w = lds_rd(&tabl[(kT2WinSc + j) * 64]);
             accr[j].x = fmaf(z[j].x, w.x, accr[j].x);
             accr[j].y = fmaf(z[j].y, w.y, accr[j].y);
         }
@@ -684,11 +765,13 @@ __global__ void __launch_bounds__(64 * kRRWaves, GL_RR_OCC) k_gl2048_regring(Ali
 #pragma unroll
         for (int j = 0; j < OVR; ++j) { accr[j] = accr[j + HS]; xraw[j] = xraw[j + HS]; }
 #pragma unroll
-        for (int jj = 0; jj < HS; ++jj) { accr[OVR + jj] = (v2f){0.0f, 0.0f}; xraw[OVR + jj] = xnew[jj]; }
+        for (int jj = 0; jj < HS; ++jj) { accr[OVR + jj] = (v2f){0.0f, 0.0f}; xraw[OVR + jj] = xnew[jj] + xnew_t[jj]; }
+        st.mark(12);
     }
 
     // partial sums of the N-H samples after the run's last frame
     const long long se = (long long)f1 * H;
+    st.flush(l);
     if (f1 == T) {
         float* orow = p.x_out + (long long)b * p.L + se + 2 * l;
 #pragma unroll
@@ -847,9 +930,10 @@ __global__ void __launch_bounds__(64 * kP1Waves, 1) k_gl1024_pair(Pair1024Args p
         const float ka = __any(a_nz) ? 1.0f : 0.0f;
         const float kb = __any(b_nz) ? 1.0f : 0.0f;
 
-        fft_forward_1024(z, ex, l, a3, g3, kloB, tabl);
+        Stamps st;
+        fft_forward_1024(z, ex, l, a3, g3, kloB, tabl, st);
         middle_two_frames(z, l0, ma, mb, ka, kb);
-        fft_inverse_1024(z, ex, l, a3, g3, kloB, tabl);
+        fft_inverse_1024(z, ex, l, a3, g3, kloB, tabl, st);
 
         // window, 1/1024, overlap-add: frame a then frame b (frame order, like the reference)
         {
@@ -1006,7 +1090,7 @@ int fold(gl_plan* p, const float* x_main, const float* tail, float* x_out, int B
 int ensure_table2(gl_plan* p) {
     if (p->d_fast_tab2) return 0;
     const int N = p->n_fft;
-    std::vector<float> tab((size_t)kT2Entries * 64 * 2, 0.0f);
+    std::vector<float> tab((size_t)(kT2Entries + 1) * 64 * 2, 0.0f);
     const double pi = 3.14159265358979323846;
     auto put = [&](int e, int l, double re, double im) {
         tab[((size_t)e * 64 + l) * 2] = (float)re;
@@ -1067,7 +1151,7 @@ int run_regring(gl_plan* p, const float* mag, const float* x0, float* x_out, int
     int rc = ensure_table2(p);
     if (!rc) rc = ensure_buffers(p);
     if (rc) return rc;
-    const int G = pick_run_length(p, B, T, 2 * kRRWaves);
+    const int G = pick_run_length(p, B, T, GL_RR_OCC * kRRWaves);
     const int nruns = (T + G - 1) / G;
     AlignedArgs a = {};
     a.mag = mag;
@@ -1092,6 +1176,20 @@ int run_regring(gl_plan* p, const float* mag, const float* x0, float* x_out, int
         src = dst;
         src_tail = (nruns > 1) ? dst_tail : nullptr;
     }
+#ifdef GL_STAMPS
+    {
+        unsigned long long h[24];
+        GL_HIP_CHECK(hipStreamSynchronize(st));
+        GL_HIP_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamp), sizeof(h)));
+        const double frames = (double)B * T * iters;
+        double tot = 0;
+        for (int i = 0; i < 13; ++i) tot += (double)h[i];
+        fprintf(stderr, "[GL_STAMPS] shader-clock ticks per frame per wave (G=%d, waves %llu): total %.0f\n", G, h[20], tot / frames);
+        for (int i = 0; i < 13; ++i) fprintf(stderr, "  phase %2d: %8.1f\n", i, (double)h[i] / frames);
+        memset(h, 0, sizeof(h));
+        GL_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), h, sizeof(h)));
+    }
+#endif
     if (nruns > 1) return fold(p, src, src_tail, x_out, B, T, G, nruns, st);
     return 0;
 }

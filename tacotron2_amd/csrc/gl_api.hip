@@ -120,7 +120,7 @@ int gl_plan_destroy(gl_plan* p) {
     if (!p) return 0;
     DeviceGuard guard(p->device);
     void* ptrs[] = {p->d_window, p->d_tw,     p->d_frames, p->d_xa,      p->d_xb,
-                    p->d_tail_a, p->d_tail_b, p->d_fast_tab, p->d_peaks, p->d_fast_tab2, p->d_xc};
+                    p->d_tail_a, p->d_tail_b, p->d_fast_tab, p->d_peaks, p->d_fast_tab2, p->d_magp};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     delete p;

@@ -620,39 +620,75 @@ __device__ __forceinline__ void middle_project(v2f* z, bool l0, const float* m_l
     for (int i = 4; i < 8; ++i) z[8 + i] = sel(l0, Q[11 - i], Q[7 - i]);
 }
 
+// Magnitudes as the register-ring kernel's lanes consume them.  Lane l of a frame needs the 17
+// values m[k], m[1024-k] at its 8 mirror pairs k = l + 128u (lane 0: see middle_project) and
+// m[512]: 17 dword loads per frame, rows 4100 bytes long so every load straddles three 128-byte
+// lines.  The kernel is bound by the number of line requests a CU can keep in flight (TCP
+// pending-stall 46 % of cycles), so gl_run first repacks the spectrogram once into
+// [frame][quad q][lane][4] + [frame][1024 + lane]: four aligned dwordx4 loads and one dword per
+// frame, 34 line requests instead of about 51.  4352 bytes per frame (6 % more than 4100).
+constexpr int kMagPack = 1088;
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(64) k_mag_repack(const float* __restrict__ mag, float* __restrict__ out, int T) {
+    const int l = threadIdx.x;
+    const long long fr = (long long)blockIdx.y * T + blockIdx.x;
+    const float* mrow = mag + fr * (kM + 1);
+    float* orow = out + fr * kMagPack;
+    const int bA = l, bB = l ? l : -448;
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int k = (u < 4 ? bA : bB) + 128 * u;
+        v[u] = mrow[k];
+        v[8 + u] = mrow[kM - k];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<v4f*>(orow + (q * 64 + l) * 4) = (v4f){v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+    orow[1024 + l] = mrow[512];
+}
+
 struct AlignedArgs {
     const float* x_in;      // [B][L]
     const float* tail_in;   // [B][nruns][N-H] or null (same run geometry as this launch)
-    const float* mag;       // [B][T][F]
+    const float* magp;      // [B][T][kMagPack]: magnitudes repacked per lane (k_mag_repack)
     float* x_out;           // [B][L]
     float* tail_out;        // [B][nruns][N-H]
     const v2f* tab;         // [kT2Entries][64]
-    int T, G, nruns;
+    int T, G, nruns, B;
     long long L;
 };
 
+#ifndef GL_MAG_PREFETCH
+#define GL_MAG_PREFETCH 2
+#endif
+// 12 waves in one workgroup per CU = 3 waves per SIMD (166 VGPRs fit the 168 budget); measured
+// 0.156 ms vs 0.167 ms per iteration for 2 workgroups of 4 (config 2)
 #ifndef GL_RR_WAVES
-#define GL_RR_WAVES 4
+#define GL_RR_WAVES 12
 #endif
 #ifndef GL_RR_OCC
-#define GL_RR_OCC 2
+#define GL_RR_OCC 1
 #endif
 constexpr int kRRWaves = GL_RR_WAVES;        // waves per workgroup; they only share the constant table
 
 template <int HS>
 __global__ void __launch_bounds__(64 * kRRWaves, GL_RR_OCC) k_gl2048_regring(AlignedArgs p) {
-    // one LDS array (table + per-wave transpose scratch): 32 KB + 4 x 9 KB = 69 KB -> 2 WG / CU
+    // one LDS array (table + per-wave transpose scratch): 32 KB + 12 x 9 KB = 140 KB -> 1 WG / CU
     __shared__ __attribute__((aligned(16))) v2f smem[kT2Entries * 64 + kRRWaves * kScratch];
     constexpr int H = 128 * HS;
     constexpr int OVR = 16 - HS;                 // rows shared with the next frame / next run
     constexpr int ovl = kN - H;
     const int l = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform
-    const int b = blockIdx.y;
-    const int run = blockIdx.x * kRRWaves + wave;
+    // runs of all utterances are numbered consecutively, so only the last workgroup has idle waves
+    const int grun = blockIdx.x * kRRWaves + wave;
     for (int i = threadIdx.x; i < kT2Entries * 64; i += 64 * kRRWaves) smem[i] = p.tab[i];
     __syncthreads();
-    if (run >= p.nruns) return;                  // wave-uniform; no barrier after this point
+    if (grun >= p.B * p.nruns) return;           // wave-uniform; no barrier after this point
+    const int b = grun / p.nruns;
+    const int run = grun - b * p.nruns;
     v2f* ex = smem + kT2Entries * 64 + wave * kScratch;
     const v2f* tabl = smem + l;
     const int T = p.T;
@@ -704,6 +740,21 @@ __global__ void __launch_bounds__(64 * kRRWaves, GL_RR_OCC) k_gl2048_regring(Ali
             accr[j] = (v2f){0.0f, 0.0f};
         }
     }
+    // magnitudes at the lane's 9 mirror pairs of frame `fr` (packed layout, see k_mag_repack)
+    auto load_mags = [&](int fr, float* lo, float* hi) {
+        const float* mrow = p.magp + ((long long)b * T + fr) * kMagPack + 4 * l;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            v4f t = (GL_ABL & 8) ? (v4f){1.0f, 2.0f, 3.0f, 4.0f} : *reinterpret_cast<const v4f*>(mrow + 256 * q);
+            float* dst = (q < 2) ? lo + 4 * q : hi + 4 * (q - 2);
+            dst[0] = t.x; dst[1] = t.y; dst[2] = t.z; dst[3] = t.w;
+        }
+        lo[8] = (GL_ABL & 8) ? 1.0f : mrow[1024 - 3 * l];
+        hi[8] = lo[8];
+    };
+    float m_lo[9], m_hi[9];
+    load_mags(f0, m_lo, m_hi);
+
     // Drain the ring-fill loads here.  Otherwise the loop header inherits "xraw[8..15] still in
     // flight" from this prologue and the compiler guards every frame's window multiply with
     // s_waitcnt vmcnt(24..17), which in steady state waits for the rows it has just requested
@@ -714,10 +765,10 @@ __global__ void __launch_bounds__(64 * kRRWaves, GL_RR_OCC) k_gl2048_regring(Ali
 
     for (int n = f0; n < f1; ++n) {
         const long long sn = (long long)n * H;
-        const int lt = l;
 
         // prefetch the HS rows the next frame adds
         const bool more = (n + 1 < f1);
+        st.mark(15);
         // (both halves of each row are requested here and summed only at the end of the frame;
         // past the run's last frame they come from the zero row: no branch around the loads)
         v2f xnew[HS], xnew_t[HS];
@@ -729,20 +780,13 @@ __global__ void __launch_bounds__(64 * kRRWaves, GL_RR_OCC) k_gl2048_regring(Ali
             xnew[jj] = *reinterpret_cast<const v2f*>(xp);
             xnew_t[jj] = *reinterpret_cast<const v2f*>(tp);
         }
-        // this frame's magnitudes at the lane's 9 mirror pairs
-        float m_lo[9], m_hi[9];
-        {
-            const float* mrow = p.mag + ((long long)b * T + n) * (kM + 1);
-            const int bA = lt, bB = lt ? lt : -448;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                int k = (u < 4 ? bA : bB) + 128 * u;
-                m_lo[u] = (GL_ABL & 8) ? 1.0f + k : mrow[k];
-                m_hi[u] = (GL_ABL & 8) ? 2.0f + k : mrow[kM - k];
-            }
-            m_lo[8] = mrow[512];
-            m_hi[8] = m_lo[8];
-        }
+        // request the NEXT frame's magnitudes (this frame's were requested a frame ago: an HBM
+        // round trip is longer than the forward transform that used to cover it)
+        st.mark(13);
+#if GL_MAG_PREFETCH == 1   // variant: request at the frame top into a second register set
+        float mn_lo[9], mn_hi[9];
+        load_mags(more ? n + 1 : n, mn_lo, mn_hi);
+#endif
 
         v2f z[16];
 #pragma unroll
@@ -750,6 +794,12 @@ __global__ void __launch_bounds__(64 * kRRWaves, GL_RR_OCC) k_gl2048_regring(Ali
         st.mark(0);
         fft_forward_1024(z, ex, l, a3, g3, kloB, tabl, st);
         if (!(GL_ABL & 2)) middle_project(z, l0, m_lo, m_hi, tabl);
+        // the magnitude registers are free again: request the next frame's now, so the loads have
+        // the inverse and the next forward transform to land (an HBM round trip under load is
+        // longer than one transform) at no cost in registers
+#if GL_MAG_PREFETCH == 2
+        load_mags(more ? n + 1 : n, m_lo, m_hi);
+#endif
         st.mark(6);
         fft_inverse_1024(z, ex, l, a3, g3, kloB, tabl, st);
 #pragma unroll
@@ -766,6 +816,10 @@ __global__ void __launch_bounds__(64 * kRRWaves, GL_RR_OCC) k_gl2048_regring(Ali
         for (int j = 0; j < OVR; ++j) { accr[j] = accr[j + HS]; xraw[j] = xraw[j + HS]; }
 #pragma unroll
         for (int jj = 0; jj < HS; ++jj) { accr[OVR + jj] = (v2f){0.0f, 0.0f}; xraw[OVR + jj] = xnew[jj] + xnew_t[jj]; }
+#if GL_MAG_PREFETCH == 1
+#pragma unroll
+        for (int u = 0; u < 9; ++u) { m_lo[u] = mn_lo[u]; m_hi[u] = mn_hi[u]; }
+#endif
         st.mark(12);
     }
 
@@ -1133,7 +1187,7 @@ bool regring_ok(const gl_plan* p, const void* a, const void* b) {
 }
 
 int launch_regring(const gl_plan* p, const AlignedArgs& a, int B, hipStream_t st) {
-    dim3 grid((a.nruns + kRRWaves - 1) / kRRWaves, B);
+    dim3 grid((unsigned)(((long long)a.nruns * B + kRRWaves - 1) / kRRWaves));
     dim3 block(64 * kRRWaves);
     static const size_t pad = getenv("GL_RR_PADLDS") ? (size_t)atoi(getenv("GL_RR_PADLDS")) : 0;  // experiments
     switch (p->hop / 128) {
@@ -1153,12 +1207,19 @@ int run_regring(gl_plan* p, const float* mag, const float* x0, float* x_out, int
     if (rc) return rc;
     const int G = pick_run_length(p, B, T, GL_RR_OCC * kRRWaves);
     const int nruns = (T + G - 1) / G;
+    if (!p->d_magp) {
+        rc = gl_plan_alloc(p, (void**)&p->d_magp, (size_t)p->max_B * p->max_T * kMagPack * sizeof(float));
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(k_mag_repack, dim3(T, B), dim3(64), 0, st, mag, p->d_magp, T);
+    GL_HIP_CHECK(hipGetLastError());
     AlignedArgs a = {};
-    a.mag = mag;
+    a.magp = p->d_magp;
     a.tab = reinterpret_cast<const v2f*>(p->d_fast_tab2);
     a.T = T;
     a.G = G;
     a.nruns = nruns;
+    a.B = B;
     a.L = gl_len(p->n_fft, p->hop, T);
     const float* src = x0;
     const float* src_tail = nullptr;
@@ -1183,9 +1244,9 @@ int run_regring(gl_plan* p, const float* mag, const float* x0, float* x_out, int
         GL_HIP_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamp), sizeof(h)));
         const double frames = (double)B * T * iters;
         double tot = 0;
-        for (int i = 0; i < 13; ++i) tot += (double)h[i];
+        for (int i = 0; i < 16; ++i) tot += (double)h[i];
         fprintf(stderr, "[GL_STAMPS] shader-clock ticks per frame per wave (G=%d, waves %llu): total %.0f\n", G, h[20], tot / frames);
-        for (int i = 0; i < 13; ++i) fprintf(stderr, "  phase %2d: %8.1f\n", i, (double)h[i] / frames);
+        for (int i = 0; i < 16; ++i) fprintf(stderr, "  phase %2d: %8.1f\n", i, (double)h[i] / frames);
         memset(h, 0, sizeof(h));
         GL_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), h, sizeof(h)));
     }

@@ -24,7 +24,7 @@ struct gl_plan {
     float* d_tail_b;
     float* d_fast_tab;  // fused path constant tables (lazy)
     float* d_fast_tab2; // register-ring kernel constant table (lazy)
-    float* d_xc;        // third signal buffer (lazy)
+    float* d_magp;      // register-ring kernel: magnitudes repacked per lane [max_B][max_T][1088] (lazy)
     unsigned* d_peaks;  // [max_B] bit patterns of max|x|
     long long bytes;
 };

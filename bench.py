@@ -152,13 +152,25 @@ def main():
         iter_ms = sum(a.elapsed_time(b) for a, b in gl_ms) / (len(gl_ms) * K)
         algo_bytes = B * (T * F * 4 + 2 * L * 4)          # read mag + read x + write x
         achieved = algo_bytes / (iter_ms * 1e-3) / 1e9
+        default_cfg = (N, H, T, B, K) == (2048, 256, 861, 64, 60)
+        workload = ("BASELINE config 2: batch of 64 synthetic 10 s 80-band mels per GPU, "
+                    "mel->linear + Griffin-Lim 60 iters + peak normalise") if default_cfg else (
+                    f"non-headline geometry: batch of {B} synthetic 80-band mels, n_fft {N}, hop {H}, {T} frames, "
+                    f"mel->linear + Griffin-Lim {K} iters + peak normalise")
+        # HBM bytes per launch of the dominant kernel from the PMC passes (FETCH_SIZE x2 gfx950
+        # correction + WRITE_SIZE, separate rocprofv3 --pmc runs of this same command; see
+        # profiles/r1_traffic.json and tools_pmc_mem.sh).  Only valid for the headline workload.
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
+        if default_cfg and args.path == 0 and os.path.exists(tpath):
+            with open(tpath) as fh:
+                traffic = json.load(fh).get("hbm_bytes_per_launch")
         out = {
-            "metric": "audio-seconds reconstructed/sec (GL 60 iters, n_fft 2048)",
+            "metric": f"audio-seconds reconstructed/sec (GL {K} iters, n_fft {N})",
             "value": value, "unit": "audio-s/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: batch of 64 synthetic 10 s 80-band mels per GPU, "
-                                   "mel->linear + Griffin-Lim 60 iters + peak normalise",
+            "config": {"workload": workload,
                        "n_fft": N, "hop": H, "frames": T, "iters": K, "batch_per_gpu": B,
                        "global_batch": B * n_gpus, "audio_s_per_utt": L / SR,
                        "parallelism": f"utterance-sharded x{n_gpus}, no data-path collective",
@@ -166,7 +178,7 @@ def main():
             "x_realtime_per_gpu": value / n_gpus,
             "roofline": {"bound": "hbm", "kernel": "fused Griffin-Lim iteration (gl_run, one launch per iteration)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": iter_ms},
             "outputs_finite": finite,
         }

@@ -79,6 +79,14 @@ int gl_istft(gl_plan* plan, const float* S, float* y, int B, int T, void* stream
 int gl_mel_to_mag(gl_plan* plan, const float* filterbank, const float* mel, float* mag,
                   int n_mels, int B, int T, void* stream);
 
+/* N1  infer.py:24-29 glue fused into a-2's contraction: the decoder's output goes straight in.
+ *   logmel : [B][T][n_mels] fp32, natural-log mel as Tacotron2.inference returns it (y_pred_post);
+ *   computes dynamic_range_decompression (data.py:84-85: exp(mel) / compression_factor), the
+ *   transpose of infer.py:28 and np.dot(filterbank.T, mel).T (griffin_lim.py:18-19) in one kernel:
+ *   mag[b][t][f] = sum_m exp(logmel[b][t][m]) / compression_factor * filterbank[m][f]            */
+int gl_logmel_to_mag(gl_plan* plan, const float* filterbank, const float* logmel, float* mag,
+                     int n_mels, float compression_factor, int B, int T, void* stream);
+
 /* a-3 + a-6  reconstruct_signal_griffin_lim(mag, fft_size, hopsamp, iterations)
  *                                                     audio_utilities.py:154-188
  *   mag   : [B][T][F] fp32   (rows = time slices)
@@ -120,6 +128,16 @@ int gl_randn(float* out, long long n, uint64_t seed, void* stream);
  *              audio_utilities.py:202-204); rows with peak 0 are left untouched  */
 int gl_peak_normalise(gl_plan* plan, float* x, long long row_stride, long long len,
                       float* peaks, int mode, int B, void* stream);
+
+/* N2 / a-7  sample conversion of save_audio_to_file            audio_utilities.py:202-210
+ *   x_max = max|x|; x /= x_max; x *= 32767; int(round(x[i]))  -- in float64 with round-half-even like
+ *   the reference, so the bytes match it for the same input samples.
+ *   x : [B][row_stride] fp32 (first `len` samples used, not modified); pcm : [B][pcm_stride] int16
+ *   peaks : [B] fp32 out (x_max per row) or NULL.  The reference asserts x_max <= 1 and fails on
+ *   x_max == 0 (NaN): a device call cannot raise, so rows with x_max == 0 are written as zeros and
+ *   the caller checks `peaks` (the Python wrapper raises like the reference).                        */
+int gl_pcm16_encode(gl_plan* plan, const float* x, long long row_stride, long long len, int16_t* pcm,
+                    long long pcm_stride, float* peaks, int B, void* stream);
 
 #ifdef __cplusplus
 }

@@ -174,6 +174,38 @@ def main():
     loop = np.array([int(round(v)) for v in xr], dtype="<i2")
     assert np.array_equal(loop, expect)
     save("pcm16_known", x=x, pcm=expect)
+    # a-7 on realistic data: fp32 samples (what the GPU holds) through the reference's own
+    # arithmetic (lines 202-210 inline: float64 /=, *=, per-sample int(round()))
+    rng = np.random.default_rng(77)
+    xf = (rng.standard_normal(40000) * 0.2).astype(np.float32)
+    xf[123] = 0.0
+    xr = xf.astype(np.float64); xm = np.max(abs(xr)); xr /= xm; xr *= 32767.0
+    loop = np.array([int(round(v)) for v in xr], dtype="<i2")
+    assert np.array_equal(loop, orc.pcm16_from_float(xf.astype(np.float64)))
+    save("pcm16_random", x=xf, pcm=loop)
+
+    # ---- N1: infer.py:24-29 glue, batch of 3 (log-mel in -> samples and PCM out) -----
+    # mels = dynamic_range_decompression(y_pred_post) = exp(.)/1 (data.py:84-85, fp32 like torch);
+    # mel = mels[b].T (infer.py:28); then the body of save_mel_to_wav around the reference GL.
+    N, H, T, K, Bn = 1024, 275, 48, 12, 3
+    L = T * H + N
+    rng = np.random.default_rng(99)
+    fb = orc.mel_filterbank_slaney(22050, N, 80, 125, 7600)
+    u = rng.normal(-2.5, 1.2, size=(Bn, T + 2, 80 + 2))
+    u = (u[:, :-2] + u[:, 1:-1] + u[:, 2:]) / 3.0
+    u = (u[:, :, :-2] + u[:, :, 1:-1] + u[:, :, 2:]) / 3.0
+    logmel = u.astype(np.float32)                       # (B, T, 80) = y_pred_post layout
+    x0 = rng.standard_normal((Bn, L))
+    ys, peaks, pcms = [], [], []
+    for b in range(Bn):
+        mel = np.exp(logmel[b]).T                       # fp32, (80, T)
+        stft_modified = np.dot(fb.T, mel).T
+        y = _gl_with_x0(stft_modified, N, H, K, x0[b])
+        peak = np.max(abs(y))
+        y_norm = y / peak if peak > 1.0 else y
+        ys.append(y); peaks.append(peak); pcms.append(orc.pcm16_from_float(y_norm))
+    save("infer_glue", logmel=logmel, x0=x0.astype(np.float32), fft_size=N, hop=H, iters=K,
+         y=np.array(ys, dtype=np.float32), peak=np.array(peaks), pcm=np.array(pcms))
     print("all golden vectors written")
 
 

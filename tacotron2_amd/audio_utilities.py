@@ -211,15 +211,40 @@ def pcm16_from_float(x):
     return np.rint(x).astype('<i2')
 
 
+def pcm16_encode_device(x):
+    """Device form of the sample conversion (N2): x is a CUDA fp32 tensor (L,) or (B, L); returns
+    a little-endian int16 numpy array of the same shape.  Only the 2-byte samples cross PCIe.
+    Raises like the reference: AssertionError when max|x| > 1 (audio_utilities.py:203), ValueError
+    when max|x| == 0 (the reference's x /= 0 gives NaN and int(round(nan)) raises)."""
+    from .plan import get_plan
+    one = (x.dim() == 1)
+    xb = (x[None] if one else x).contiguous().to(torch.float32)
+    B, L = xb.shape
+    plan = get_plan(64, 16, 1, B, xb.device)      # geometry is irrelevant to the encode kernels
+    pcm, peaks = plan.pcm16_encode(xb)
+    peaks = peaks.cpu().numpy()
+    assert float(peaks.max()) <= 1.0, 'Input audio value is out of range. Should be in the range [-1.0, 1.0].'
+    if float(peaks.min()) == 0.0:
+        raise ValueError("cannot convert float NaN to integer")
+    out = pcm.cpu().numpy().astype('<i2', copy=False)
+    return out[0] if one else out
+
+
 def save_audio_to_file(x, sample_rate, outfile='out.wav'):
-    """Write a mono 16-bit PCM WAV (audio_utilities.py:191-215).  Host-side: the
-    per-sample Python loop of the reference is vectorised, the bytes are the same.
-    Unlike the reference, `x` is not modified in place."""
-    if isinstance(x, torch.Tensor):
-        x = x.detach().cpu().numpy()
-    print(np.max(x))
-    print(np.min(x))
-    data = pcm16_from_float(x)
+    """Write a mono 16-bit PCM WAV (audio_utilities.py:191-215).  A CUDA tensor is encoded on the
+    device (gl_pcm16_encode) and only the int16 samples are copied back; a numpy array / CPU tensor
+    is encoded on the host (the per-sample Python loop of the reference, vectorised).  Same bytes
+    either way.  Unlike the reference, `x` is not modified in place."""
+    if isinstance(x, torch.Tensor) and x.is_cuda:
+        print(float(x.max()))
+        print(float(x.min()))
+        data = pcm16_encode_device(x)
+    else:
+        if isinstance(x, torch.Tensor):
+            x = x.detach().cpu().numpy()
+        print(np.max(x))
+        print(np.min(x))
+        data = pcm16_from_float(x)
     f = wave.open(outfile, 'w')
     f.setparams((1, 2, int(sample_rate), 0, "NONE", "Uncompressed"))
     f.writeframes(data.tobytes())

@@ -177,7 +177,20 @@ int gl_mel_to_mag(gl_plan* p, const float* filterbank, const float* mel, float* 
     if (!filterbank || !mel || !mag) return gl_set_error(GL_ERR_INVALID, "gl_mel_to_mag: NULL buffer");
     if (n_mels < 1 || n_mels > 4096) return gl_set_error(GL_ERR_INVALID, "gl_mel_to_mag: n_mels=%d", n_mels);
     DeviceGuard guard(p->device);
-    return gl_mel_launch(filterbank, mel, mag, n_mels, p->n_fft / 2 + 1, B, T, (hipStream_t)stream);
+    return gl_mel_launch(filterbank, mel, mag, n_mels, p->n_fft / 2 + 1, B, T, false, 1.0f, (hipStream_t)stream);
+}
+
+int gl_logmel_to_mag(gl_plan* p, const float* filterbank, const float* logmel, float* mag, int n_mels,
+                     float compression_factor, int B, int T, void* stream) {
+    int rc = check_call(p, B, T, "gl_logmel_to_mag");
+    if (rc) return rc;
+    if (!filterbank || !logmel || !mag) return gl_set_error(GL_ERR_INVALID, "gl_logmel_to_mag: NULL buffer");
+    if (n_mels < 1 || n_mels > 4096) return gl_set_error(GL_ERR_INVALID, "gl_logmel_to_mag: n_mels=%d", n_mels);
+    if (!(compression_factor > 0.0f))
+        return gl_set_error(GL_ERR_INVALID, "gl_logmel_to_mag: compression_factor must be > 0");
+    DeviceGuard guard(p->device);
+    return gl_mel_launch(filterbank, logmel, mag, n_mels, p->n_fft / 2 + 1, B, T, true, compression_factor,
+                         (hipStream_t)stream);
 }
 
 int gl_run(gl_plan* p, const float* mag, const float* x0, float* x_out, int iters, int B, int T, void* stream) {
@@ -206,6 +219,16 @@ int gl_peak_normalise(gl_plan* p, float* x, long long row_stride, long long len,
         return gl_set_error(GL_ERR_INVALID, "gl_peak_normalise: bad len/stride/mode");
     DeviceGuard guard(p->device);
     return gl_peak_launch(p, x, row_stride, len, peaks, mode, B, (hipStream_t)stream);
+}
+
+int gl_pcm16_encode(gl_plan* p, const float* x, long long row_stride, long long len, int16_t* pcm,
+                    long long pcm_stride, float* peaks, int B, void* stream) {
+    if (!p || !x || !pcm) return gl_set_error(GL_ERR_INVALID, "gl_pcm16_encode: NULL argument");
+    if (B < 1 || B > p->max_B) return gl_set_error(GL_ERR_INVALID, "gl_pcm16_encode: B=%d outside [1, %d]", B, p->max_B);
+    if (len < 1 || row_stride < len || pcm_stride < len)
+        return gl_set_error(GL_ERR_INVALID, "gl_pcm16_encode: bad len/stride");
+    DeviceGuard guard(p->device);
+    return gl_pcm16_launch(p, x, row_stride, len, pcm, pcm_stride, peaks, B, (hipStream_t)stream);
 }
 
 }  // extern "C"

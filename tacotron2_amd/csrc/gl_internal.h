@@ -57,13 +57,16 @@ int gl_fast_run(gl_plan* p, const float* mag, const float* x0, float* x_out, int
                 hipStream_t st);
 
 // ---- mel inversion (MFMA): gl_mel.hip ---------------------------------------------
-int gl_mel_launch(const float* fb, const float* mel, float* mag, int n_mels, int F, int B, int T, hipStream_t st);
+int gl_mel_launch(const float* fb, const float* mel, float* mag, int n_mels, int F, int B, int T, bool logmel,
+                  float compression_factor, hipStream_t st);
 
 // ---- misc: gl_misc.hip -------------------------------------------------------------
 int gl_randn_launch(float* out, long long n, uint64_t seed, hipStream_t st);
 int gl_peak_launch(gl_plan* p, float* x, long long row_stride, long long len, float* peaks, int mode, int B,
                    hipStream_t st);
 int gl_copy_rows(float* dst, const float* src, long long n, hipStream_t st);
+int gl_pcm16_launch(gl_plan* p, const float* x, long long row_stride, long long len, int16_t* pcm,
+                    long long pcm_stride, float* peaks, int B, hipStream_t st);
 
 // ---- small complex helpers ------------------------------------------------------------
 __device__ __forceinline__ float2 c_add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }

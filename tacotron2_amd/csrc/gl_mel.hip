@@ -21,9 +21,15 @@ constexpr int kTileT = 32;      // rows (t) per wave
 constexpr int kTileF = 128;     // cols (f) per wave: 4 accumulators of 32
 constexpr int kWaves = 4;       // waves per workgroup, stacked along t
 
+// LOGMEL = false: mel is [B][K][T] linear amplitude (what save_mel_to_wav receives).
+// LOGMEL = true : mel is [B][T][K] natural-log amplitude, the decoder's output layout; the kernel
+//                 applies dynamic_range_decompression (data.py:84-85: exp(mel) / compression_factor)
+//                 and the transpose of infer.py:27-28 on the fly, so no (80, T) array is materialised.
+template <bool LOGMEL>
 __global__ void __launch_bounds__(64 * kWaves) k_mel_to_mag(const float* __restrict__ fb,
                                                             const float* __restrict__ mel,
-                                                            float* __restrict__ mag, int K, int F, int T) {
+                                                            float* __restrict__ mag, int K, int F, int T,
+                                                            float inv_cf) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int b = blockIdx.z;
@@ -35,7 +41,8 @@ __global__ void __launch_bounds__(64 * kWaves) k_mel_to_mag(const float* __restr
     const int lk = lane >> 5;
     const int t = t0 + li;
     const bool t_ok = t < T;
-    const float* a_ptr = mel + (long long)b * K * T + (t_ok ? t : 0);
+    const float* a_ptr = LOGMEL ? mel + ((long long)b * T + (t_ok ? t : 0)) * K
+                                : mel + (long long)b * K * T + (t_ok ? t : 0);
 
     f32x16 acc[4];
 #pragma unroll
@@ -56,7 +63,7 @@ __global__ void __launch_bounds__(64 * kWaves) k_mel_to_mag(const float* __restr
         const int k = k0 + lk;
         const bool k_ok = k < K;
         const int kk = k_ok ? k : 0;
-        float a = a_ptr[(long long)kk * T];
+        float a = LOGMEL ? expf(a_ptr[kk]) * inv_cf : a_ptr[(long long)kk * T];
         a = (k_ok && t_ok) ? a : 0.0f;
         float bv[4];
 #pragma unroll
@@ -83,9 +90,14 @@ __global__ void __launch_bounds__(64 * kWaves) k_mel_to_mag(const float* __restr
 
 }  // namespace
 
-int gl_mel_launch(const float* fb, const float* mel, float* mag, int n_mels, int F, int B, int T, hipStream_t st) {
+int gl_mel_launch(const float* fb, const float* mel, float* mag, int n_mels, int F, int B, int T, bool logmel,
+                  float compression_factor, hipStream_t st) {
     dim3 grid((F + kTileF - 1) / kTileF, (T + kTileT * kWaves - 1) / (kTileT * kWaves), B);
-    hipLaunchKernelGGL(k_mel_to_mag, grid, dim3(64 * kWaves), 0, st, fb, mel, mag, n_mels, F, T);
+    if (logmel)
+        hipLaunchKernelGGL(k_mel_to_mag<true>, grid, dim3(64 * kWaves), 0, st, fb, mel, mag, n_mels, F, T,
+                           1.0f / compression_factor);
+    else
+        hipLaunchKernelGGL(k_mel_to_mag<false>, grid, dim3(64 * kWaves), 0, st, fb, mel, mag, n_mels, F, T, 1.0f);
     GL_HIP_CHECK(hipGetLastError());
     return 0;
 }

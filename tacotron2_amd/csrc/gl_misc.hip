@@ -82,7 +82,44 @@ __global__ void __launch_bounds__(kThreads) k_peak_scale(float* __restrict__ x, 
         row[i] = row[i] / peak;
 }
 
+// ---- 16-bit PCM encode (audio_utilities.py:202-210) ------------------------------------
+// x /= max|x|; x *= 32767; int(round(x[i])) -- the reference works in float64 and Python's round
+// is half-to-even, so the same three float64 operations (IEEE divide, multiply, v_rndne_f64) on the
+// fp32 samples give the reference's bytes for the same input.
+__global__ void __launch_bounds__(kThreads) k_pcm16(const float* __restrict__ x, long long row_stride, long long len,
+                                                    const unsigned* __restrict__ peaks, int16_t* __restrict__ pcm,
+                                                    long long pcm_stride, float* __restrict__ peaks_out) {
+    const int b = blockIdx.y;
+    const float peakf = __uint_as_float(peaks[b]);
+    if (peaks_out && blockIdx.x == 0 && threadIdx.x == 0) peaks_out[b] = peakf;
+    const double peak = (double)peakf;
+    const float* row = x + (long long)b * row_stride;
+    int16_t* orow = pcm + (long long)b * pcm_stride;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < len;
+         i += (long long)gridDim.x * blockDim.x) {
+        double v = (double)row[i];
+        v = v / peak;          // peak == 0 -> NaN like the reference; the cast below then stores 0
+        v = v * 32767.0;
+        v = rint(v);
+        orow[i] = (peakf > 0.0f) ? (int16_t)(int)v : (int16_t)0;
+    }
+}
+
 }  // namespace
+
+int gl_pcm16_launch(gl_plan* p, const float* x, long long row_stride, long long len, int16_t* pcm,
+                    long long pcm_stride, float* peaks, int B, hipStream_t st) {
+    GL_HIP_CHECK(hipMemsetAsync(p->d_peaks, 0, sizeof(unsigned) * (size_t)B, st));
+    long long blocks = (len + kThreads * 8 - 1) / (kThreads * 8);
+    if (blocks > 64) blocks = 64;
+    if (blocks < 1) blocks = 1;
+    dim3 grid((unsigned)blocks, B);
+    hipLaunchKernelGGL(k_absmax, grid, dim3(kThreads), 0, st, x, row_stride, len, p->d_peaks);
+    GL_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_pcm16, grid, dim3(kThreads), 0, st, x, row_stride, len, p->d_peaks, pcm, pcm_stride, peaks);
+    GL_HIP_CHECK(hipGetLastError());
+    return 0;
+}
 
 int gl_randn_launch(float* out, long long n, uint64_t seed, hipStream_t st) {
     long long nq = (n + 3) >> 2;

@@ -6,7 +6,8 @@ TRANSPOSE of the mel filterbank (not a pseudo-inverse), Griffin-Lim with the
 ``params`` geometry, peak-normalise only if max|x| > 1, write
 ``<audio_out_path>/<filename>.wav``, return the (F, T) linear magnitude.
 The contraction runs on MFMA (gl_mel_to_mag) and the loop on the fused HIP
-kernels (gl_run); only the 16-bit WAV encode stays on the host.
+kernels (gl_run); the 16-bit sample conversion runs on the device as well (gl_pcm16_encode), the
+host only writes the WAV container.
 """
 import os
 from os.path import join
@@ -89,6 +90,77 @@ def mel_to_audio(mel_spectrogram, *, basis=None, n_fft=None, hop=None, iteration
     return x, mag
 
 
+def logmel_to_audio(y_pred_post, *, compression_factor=1.0, basis=None, n_fft=None, hop=None, iterations=None,
+                    x_init=None, seed=None, rng="numpy", normalize="reference", device=None):
+    """infer.py:24-29 without the host round trip: the decoder output goes in as it is.
+
+    y_pred_post: (B, T, n_mels) or (T, n_mels) natural-log mel (Tacotron2.inference's second
+    result), numpy or torch.  dynamic_range_decompression (data.py:84-85), the transpose of
+    infer.py:28 and the filterbank contraction run in ONE kernel (gl_logmel_to_mag); then Griffin-Lim
+    and the normalisation of save_mel_to_wav.  Unlike the reference (batch forced to 1,
+    model.py:530) any batch size is accepted.  Returns (waveforms (B, L), magnitude (B, T, F))."""
+    n_fft = int(params.n_fft if n_fft is None else n_fft)
+    hop = int(params.frame_hop if hop is None else hop)
+    iterations = int(params.griffin_lim_iters if iterations is None else iterations)
+    dev = audio_utilities._pick_device(device, y_pred_post)
+    lm, _ = audio_utilities._to_device(y_pred_post, dev, torch.float32)
+    if lm.dim() == 2:
+        lm = lm[None]
+    if lm.dim() != 3:
+        raise ValueError("y_pred_post must be (T, n_mels) or (B, T, n_mels)")
+    lm = lm.contiguous()
+    B, T, n_mels = lm.shape
+    if basis is None:
+        if n_fft != params.n_fft or n_mels != params.n_mel_channels:
+            fb_dev = torch.from_numpy(filters.mel(sr=params.sampling_rate, n_fft=n_fft, n_mels=n_mels,
+                                                  fmin=params.f_min, fmax=params.f_max)).to(dev)
+        else:
+            fb_dev = _device_filterbank(filterbank, dev)
+    else:
+        b, _ = audio_utilities._to_device(basis, dev, torch.float32)
+        fb_dev = b.t().contiguous()
+    if tuple(fb_dev.shape) != (n_mels, n_fft // 2 + 1):
+        raise ValueError(f"basis/filterbank shape {tuple(fb_dev.shape)} does not match "
+                         f"({n_mels}, {n_fft // 2 + 1})")
+    plan = get_plan(n_fft, hop, T, B, dev)
+    mag = plan.logmel_to_mag(fb_dev, lm, compression_factor)
+    L = plan.signal_length(T)
+    x0 = audio_utilities._start_signal(B, L, x_init, seed, rng, plan, dev)
+    x = plan.run(mag, x0, iterations, out=x0)
+    if normalize == "reference":
+        plan.peak_normalise(x, mode=0)
+    elif normalize == "peak":
+        plan.peak_normalise(x, mode=1)
+    elif normalize is not None:
+        raise ValueError("normalize must be 'reference', 'peak' or None")
+    return x, mag
+
+
+def infer_to_wav(y_pred_post, filenames=None, **kw):
+    """Batched counterpart of infer.py:27-29: log-mel batch -> one WAV per utterance under
+    params.audio_out_path ("Inference.wav" for a single utterance, like the reference).  The PCM
+    encode runs on the device too (gl_pcm16_encode).  Returns the list of paths."""
+    x, _ = logmel_to_audio(y_pred_post, **kw)
+    B = x.shape[0]
+    if filenames is None:
+        filenames = ["Inference"] if B == 1 else ["Inference_%d" % i for i in range(B)]
+    if len(filenames) != B:
+        raise ValueError("one filename per utterance")
+    out_dir = params.audio_out_path
+    os.makedirs(out_dir, exist_ok=True)
+    pcm = audio_utilities.pcm16_encode_device(x)
+    paths = []
+    import wave
+    for i, name in enumerate(filenames):
+        path = join(out_dir, name + '.wav')
+        f = wave.open(path, 'w')
+        f.setparams((1, 2, int(params.sampling_rate), 0, "NONE", "Uncompressed"))
+        f.writeframes(pcm[i].tobytes())
+        f.close()
+        paths.append(path)
+    return paths
+
+
 def save_mel_to_wav(mel_spectrogram, filename='out', *, basis=None, iterations=None, x_init=None, seed=None,
                     rng="numpy", device=None, write_wav=True):
     """Reference entry point (griffin_lim.py:17-35); see the module docstring.
@@ -101,8 +173,7 @@ def save_mel_to_wav(mel_spectrogram, filename='out', *, basis=None, iterations=N
     if write_wav:
         out_dir = params.audio_out_path
         os.makedirs(out_dir, exist_ok=True)
-        audio_utilities.save_audio_to_file(x[0].cpu().numpy().astype(np.float64), params.sampling_rate,
-                                           outfile=join(out_dir, filename + '.wav'))
+        audio_utilities.save_audio_to_file(x[0], params.sampling_rate, outfile=join(out_dir, filename + '.wav'))
     # griffin_lim.py:35 returns stft_modified.T == the (F, T) linear magnitude
     lin = mag[0].t()
     if isinstance(mel_spectrogram, torch.Tensor):

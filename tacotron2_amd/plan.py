@@ -115,6 +115,19 @@ class Plan:
                                                _stream_ptr(self.device)), "gl_mel_to_mag")
         return out
 
+    def logmel_to_mag(self, filterbank, logmel, compression_factor=1.0, out=None):
+        """filterbank (n_mels, F), logmel (B, T, n_mels) natural-log mel (the decoder's layout)
+        -> mag (B, T, F); exp, 1/compression_factor and the transpose are fused (infer.py:27-28)."""
+        B, T, n_mels = logmel.shape
+        if out is None:
+            out = torch.empty((B, T, self.n_bins), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.gl_logmel_to_mag(self._h, self._f32(filterbank, (n_mels, self.n_bins)),
+                                                  self._f32(logmel), self._f32(out, (B, T, self.n_bins)), n_mels,
+                                                  float(compression_factor), B, T,
+                                                  _stream_ptr(self.device)), "gl_logmel_to_mag")
+        return out
+
     def run(self, mag, x0, iterations, out=None):
         """mag (B, T, F), x0 (B, L) -> x (B, L) after `iterations` Griffin-Lim iterations."""
         B, T, F = mag.shape
@@ -143,6 +156,18 @@ class Plan:
             _lib.check(self._lib.gl_peak_normalise(self._h, self._f32(x), L, L, self._f32(peaks), int(mode), B,
                                                    _stream_ptr(self.device)), "gl_peak_normalise")
         return peaks
+
+
+    def pcm16_encode(self, x):
+        """x (B, L) fp32 -> (int16 (B, L) on device, peaks (B,)): the sample conversion of
+        save_audio_to_file (audio_utilities.py:202-210), float64 arithmetic, round-half-even."""
+        B, L = x.shape
+        pcm = torch.empty((B, L), dtype=torch.int16, device=self.device)
+        peaks = torch.empty((B,), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.gl_pcm16_encode(self._h, self._f32(x), L, L, ctypes.c_void_p(pcm.data_ptr()), L,
+                                                 self._f32(peaks), B, _stream_ptr(self.device)), "gl_pcm16_encode")
+        return pcm, peaks
 
 
 _cache = {}

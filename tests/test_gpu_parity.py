@@ -343,3 +343,78 @@ def test_config5_geometry_batch32():
         mi = mag[i].cpu().numpy().astype(np.float64)
         ref = orc.griffin_lim_vec(mi, N, H, K, x0[i].cpu().numpy().astype(np.float64))
         assert peak_err(y[i].cpu().numpy(), ref) <= TOL_GL
+
+
+# ---- N2: 16-bit sample conversion on the device (audio_utilities.py:202-210) --------------
+def test_pcm16_device_is_byte_exact(golden):
+    """Same bytes as the reference's float64 /=, *=, int(round()) loop for the same fp32 samples."""
+    k = golden("pcm16_known")
+    got = au.pcm16_encode_device(torch.from_numpy(k["x"].astype(np.float32)).cuda())
+    # 1/65534 etc. are not fp32 numbers: compare with the oracle on the SAME fp32 samples
+    assert np.array_equal(got, orc.pcm16_from_float(k["x"].astype(np.float32).astype(np.float64)))
+    r = golden("pcm16_random")
+    x = torch.from_numpy(r["x"]).cuda()
+    got = au.pcm16_encode_device(x)
+    assert got.dtype == np.dtype("<i2") and np.array_equal(got, r["pcm"])
+    # batch rows are encoded with their own peak
+    xb = torch.stack([x, 0.5 * x, -0.25 * x])
+    gb = au.pcm16_encode_device(xb)
+    for i in range(3):
+        assert np.array_equal(gb[i], orc.pcm16_from_float(xb[i].cpu().numpy().astype(np.float64)))
+    # exact ties: 16383.5 -> 16384, 0.5 -> 0, 1.5 -> 2, 2.5 -> 2 (half to even)
+    t = torch.tensor([1.0, 16383.5 / 32767.0, 0.5 / 32767.0, 1.5 / 32767.0, 2.5 / 32767.0], dtype=torch.float64)
+    tf = t.to(torch.float32).cuda()
+    assert np.array_equal(au.pcm16_encode_device(tf), orc.pcm16_from_float(tf.cpu().numpy().astype(np.float64)))
+
+
+def test_pcm16_device_error_behaviour():
+    with pytest.raises(AssertionError):                      # audio_utilities.py:203
+        au.pcm16_encode_device(torch.tensor([0.0, 1.5], device="cuda"))
+    with pytest.raises(ValueError):                          # x /= 0 -> NaN -> int(round(nan))
+        au.pcm16_encode_device(torch.zeros(16, device="cuda"))
+
+
+def test_save_audio_to_file_device_and_host_write_the_same_bytes(golden, tmp_path):
+    x = torch.from_numpy(golden("pcm16_random")["x"]).cuda()
+    au.save_audio_to_file(x, 22050, str(tmp_path / "dev.wav"))
+    au.save_audio_to_file(x.cpu().numpy().astype(np.float64), 22050, str(tmp_path / "host.wav"))
+    assert (tmp_path / "dev.wav").read_bytes() == (tmp_path / "host.wav").read_bytes()
+
+
+# ---- N1: infer.py:24-29 glue on the device ---------------------------------------------------
+def test_logmel_to_mag_matches_exp_transpose_dot(golden):
+    d = golden("infer_glue")
+    fb = filters.mel(22050, 1024, 80, 125, 7600)
+    lm = torch.from_numpy(d["logmel"]).cuda()
+    p = get_plan(1024, 275, lm.shape[1], lm.shape[0])
+    for cf in (1.0, 2.5):
+        got = p.logmel_to_mag(torch.from_numpy(fb).cuda(), lm, cf).cpu().numpy()
+        ref = np.einsum("mf,btm->btf", fb.astype(np.float64), np.exp(d["logmel"].astype(np.float64)) / cf)
+        assert peak_err(got, ref) <= 2e-6
+    # same numbers as the two-step path (exp + transpose on the host, then gl_mel_to_mag)
+    mel = torch.from_numpy(np.ascontiguousarray(np.exp(d["logmel"]).transpose(0, 2, 1))).cuda()
+    two = p.mel_to_mag(torch.from_numpy(fb).cuda(), mel).cpu().numpy()
+    one = p.logmel_to_mag(torch.from_numpy(fb).cuda(), lm).cpu().numpy()
+    assert peak_err(one, two) <= 1e-6
+
+
+def test_infer_glue_batch(golden, tmp_path, monkeypatch):
+    """log-mel batch in -> waveforms and WAV files out, against the reference-generated fixture."""
+    d = golden("infer_glue")
+    K = int(d["iters"])
+    x, mag = griffin_lim.logmel_to_audio(d["logmel"], iterations=K, x_init=d["x0"], normalize=None)
+    assert tuple(mag.shape) == (3, 48, 513)
+    for b in range(3):
+        assert peak_err(x[b].cpu().numpy(), d["y"][b]) <= TOL_GL
+    monkeypatch.setattr(griffin_lim.params, "audio_out_path", str(tmp_path))
+    paths = griffin_lim.infer_to_wav(torch.from_numpy(d["logmel"]).cuda(), iterations=K, x_init=d["x0"])
+    import wave
+    assert len(paths) == 3
+    for b, path in enumerate(paths):
+        w = wave.open(path)
+        assert (w.getnchannels(), w.getsampwidth(), w.getframerate()) == (1, 2, 22050)
+        pcm = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2")
+        assert np.max(np.abs(pcm.astype(int) - d["pcm"][b].astype(int))) <= 34   # 1e-3 of full scale
+    # a single (T, n_mels) utterance is written as Inference.wav like infer.py:29
+    one = griffin_lim.infer_to_wav(d["logmel"][0], iterations=2, seed=3)
+    assert one[0].endswith("Inference.wav")

@@ -73,6 +73,28 @@ def test_pcm16_known_answers(golden):
         orc.pcm16_from_float(np.array([0.0, 1.5]))
 
 
+def test_pcm16_random_matches_reference_loop(golden):
+    """fp32 samples through the oracle's conversion == the reference's per-sample int(round()) loop."""
+    d = golden("pcm16_random")
+    assert np.array_equal(orc.pcm16_from_float(d["x"].astype(np.float64)), d["pcm"])
+
+
+def test_infer_glue_fixture(golden):
+    """N1 fixture (infer.py:24-29): exp -> transpose -> save_mel_to_wav body, batch of 3."""
+    d = golden("infer_glue")
+    N, H, K = int(d["fft_size"]), int(d["hop"]), int(d["iters"])
+    fb = orc.mel_filterbank_slaney(22050, N, 80, 125, 7600)
+    for b in range(d["logmel"].shape[0]):
+        mel = np.exp(d["logmel"][b]).T
+        mag = orc.mel_to_linear(fb, mel)
+        y = orc.griffin_lim_vec(mag, N, H, K, d["x0"][b].astype(np.float64))
+        peak = np.max(np.abs(y))
+        assert abs(peak - float(d["peak"][b])) <= 1e-6 * peak
+        assert np.max(np.abs(y - d["y"][b])) <= 2e-6 * peak
+        pcm = orc.pcm16_from_float(orc.peak_normalise(y))
+        assert np.max(np.abs(pcm.astype(int) - d["pcm"][b].astype(int))) <= 1
+
+
 def test_mel_inversion(golden):
     d = golden("mel_inv_2048")
     got = np.dot(d["basis"], d["mel"]).T

@@ -119,6 +119,20 @@ int gl_plan_set_run_frames(gl_plan* plan, int frames);
  * needed.  out : [n] fp32.  Deterministic in (seed, index).                     */
 int gl_randn(float* out, long long n, uint64_t seed, void* stream);
 
+/* As gl_randn, but element i of the call is element offset+i of the seed's stream: ranks that
+ * each hold a slice of one long start signal (config 4) fill it consistently.              */
+int gl_randn_at(float* out, long long n, uint64_t seed, long long offset, void* stream);
+
+/* Long-form stitching (BASELINE config 4; the reference reconstructs one utterance in
+ * one piece, audio_utilities.py:154-188, so this has no line there): out[out_offset + i] +=
+ * w(i) * chunk[i] for i in [0, chunk_len), samples falling outside [0, out_len) are skipped.
+ * w ramps 0 -> 1 over the first fade_in samples and 1 -> 0 over the last fade_out samples
+ * (fade_in + fade_out <= chunk_len; 0 = hard cut); two chunks whose fades overlap over the
+ * same F samples sum to weight exactly 1.  `out` must be zero-filled before the first chunk
+ * and the calls that overlap must be ordered on one stream.                                 */
+int gl_stitch_add(float* out, long long out_len, const float* chunk, long long chunk_len, long long out_offset,
+                  long long fade_in, long long fade_out, void* stream);
+
 /* a-2 (normalise step)  max_sample = max|x|; if max_sample > 1: x /= max_sample
  *                                                        griffin_lim.py:27-29
  *   x : [B][row_stride] fp32, first `len` samples of each row are used, in place

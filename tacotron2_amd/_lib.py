@@ -35,6 +35,9 @@ SIGNATURES = {
     "gl_run": (ctypes.c_int, [_plan_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                               ctypes.c_void_p]),
     "gl_randn": (ctypes.c_int, [_c_float_p, ctypes.c_longlong, ctypes.c_uint64, ctypes.c_void_p]),
+    "gl_randn_at": (ctypes.c_int, [_c_float_p, ctypes.c_longlong, ctypes.c_uint64, ctypes.c_longlong, ctypes.c_void_p]),
+    "gl_stitch_add": (ctypes.c_int, [_c_float_p, ctypes.c_longlong, _c_float_p, ctypes.c_longlong, ctypes.c_longlong,
+                                     ctypes.c_longlong, ctypes.c_longlong, ctypes.c_void_p]),
     "gl_peak_normalise": (ctypes.c_int, [_plan_p, _c_float_p, ctypes.c_longlong, ctypes.c_longlong, _c_float_p,
                                          ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "gl_pcm16_encode": (ctypes.c_int, [_plan_p, _c_float_p, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_void_p,

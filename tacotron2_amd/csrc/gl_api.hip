@@ -208,7 +208,24 @@ int gl_run(gl_plan* p, const float* mag, const float* x0, float* x_out, int iter
 int gl_randn(float* out, long long n, uint64_t seed, void* stream) {
     if (!out || n < 0) return gl_set_error(GL_ERR_INVALID, "gl_randn: bad argument");
     if (n == 0) return 0;
-    return gl_randn_launch(out, n, seed, (hipStream_t)stream);
+    return gl_randn_launch(out, n, seed, 0, (hipStream_t)stream);
+}
+
+int gl_randn_at(float* out, long long n, uint64_t seed, long long offset, void* stream) {
+    if (!out || n < 0 || offset < 0) return gl_set_error(GL_ERR_INVALID, "gl_randn_at: bad argument");
+    if (n == 0) return 0;
+    return gl_randn_launch(out, n, seed, offset, (hipStream_t)stream);
+}
+
+int gl_stitch_add(float* out, long long out_len, const float* chunk, long long chunk_len, long long out_offset,
+                  long long fade_in, long long fade_out, void* stream) {
+    if (!out || !chunk || out_len < 0 || chunk_len < 0 || fade_in < 0 || fade_out < 0)
+        return gl_set_error(GL_ERR_INVALID, "gl_stitch_add: bad argument");
+    if (fade_in + fade_out > chunk_len)
+        return gl_set_error(GL_ERR_INVALID, "gl_stitch_add: fades (%lld + %lld) longer than the chunk (%lld)", fade_in,
+                            fade_out, chunk_len);
+    if (chunk_len == 0) return 0;
+    return gl_stitch_launch(out, out_len, chunk, chunk_len, out_offset, fade_in, fade_out, (hipStream_t)stream);
 }
 
 int gl_peak_normalise(gl_plan* p, float* x, long long row_stride, long long len, float* peaks, int mode, int B,

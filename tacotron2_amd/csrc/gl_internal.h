@@ -61,7 +61,9 @@ int gl_mel_launch(const float* fb, const float* mel, float* mag, int n_mels, int
                   float compression_factor, hipStream_t st);
 
 // ---- misc: gl_misc.hip -------------------------------------------------------------
-int gl_randn_launch(float* out, long long n, uint64_t seed, hipStream_t st);
+int gl_randn_launch(float* out, long long n, uint64_t seed, long long offset, hipStream_t st);
+int gl_stitch_launch(float* out, long long out_len, const float* chunk, long long chunk_len, long long out_offset,
+                     long long fade_in, long long fade_out, hipStream_t st);
 int gl_peak_launch(gl_plan* p, float* x, long long row_stride, long long len, float* peaks, int mode, int B,
                    hipStream_t st);
 int gl_copy_rows(float* dst, const float* src, long long n, hipStream_t st);

@@ -20,11 +20,15 @@ __device__ __forceinline__ float u01(uint32_t r) {  // (0, 1]
 }
 
 // Stands in for np.random.randn(len_samples) (audio_utilities.py:176) in
-// throughput runs; four normals per counter value.
-__global__ void __launch_bounds__(kThreads) k_randn(float* __restrict__ out, long long n, uint64_t seed) {
-    long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    long long nq = (n + 3) >> 2;
-    for (; q < nq; q += (long long)gridDim.x * blockDim.x) {
+// throughput runs; four normals per counter value.  Element i of the call is element
+// `offset + i` of the seed's stream, so a rank can fill just its slice of a long signal.
+__global__ void __launch_bounds__(kThreads) k_randn(float* __restrict__ out, long long n, uint64_t seed,
+                                                    long long offset) {
+    const long long q0 = offset >> 2;
+    const long long nq = ((offset + n + 3) >> 2) - q0;
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; t < nq; t += (long long)gridDim.x * blockDim.x) {
+        const long long q = q0 + t;
         uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), 0u, 0u};
         uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
@@ -39,10 +43,29 @@ __global__ void __launch_bounds__(kThreads) k_randn(float* __restrict__ out, lon
         __sincosf(6.283185307179586f * u01(c[1]), &s0, &c0);
         __sincosf(6.283185307179586f * u01(c[3]), &s1, &c1);
         float v[4] = {r0 * c0, r0 * s0, r1 * c1, r1 * s1};
-        long long base = q << 2;
+        const long long base = (q << 2) - offset;      // index into `out` of this quad's first normal
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (base + j < n) out[base + j] = v[j];
+            if (base + j >= 0 && base + j < n) out[base + j] = v[j];
+    }
+}
+
+// ---- chunk stitching (long-form reconstruction) -------------------------------------------
+// out[out_offset + i] += w(i) * chunk[i]: w ramps 0 -> 1 over the first fade_in samples and
+// 1 -> 0 over the last fade_out samples (half-sample centred, so two chunks whose fades overlap
+// by the same length sum to exactly one), 1 in between.
+__global__ void __launch_bounds__(kThreads) k_stitch_add(float* __restrict__ out, long long out_len,
+                                                         const float* __restrict__ chunk, long long chunk_len,
+                                                         long long out_offset, long long fade_in,
+                                                         long long fade_out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < chunk_len;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long o = out_offset + i;
+        if (o < 0 || o >= out_len) continue;
+        float w = 1.0f;
+        if (i < fade_in) w = ((float)i + 0.5f) / (float)fade_in;
+        if (chunk_len - 1 - i < fade_out) w *= ((float)(chunk_len - 1 - i) + 0.5f) / (float)fade_out;
+        out[o] += w * chunk[i];
     }
 }
 
@@ -121,12 +144,23 @@ int gl_pcm16_launch(gl_plan* p, const float* x, long long row_stride, long long 
     return 0;
 }
 
-int gl_randn_launch(float* out, long long n, uint64_t seed, hipStream_t st) {
-    long long nq = (n + 3) >> 2;
+int gl_stitch_launch(float* out, long long out_len, const float* chunk, long long chunk_len, long long out_offset,
+                     long long fade_in, long long fade_out, hipStream_t st) {
+    long long blocks = (chunk_len + kThreads * 4 - 1) / (kThreads * 4);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_stitch_add, dim3((unsigned)blocks), dim3(kThreads), 0, st, out, out_len, chunk, chunk_len,
+                       out_offset, fade_in, fade_out);
+    GL_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int gl_randn_launch(float* out, long long n, uint64_t seed, long long offset, hipStream_t st) {
+    long long nq = ((offset + n + 3) >> 2) - (offset >> 2);
     long long blocks = (nq + kThreads - 1) / kThreads;
     if (blocks > 8192) blocks = 8192;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_randn, dim3((unsigned)blocks), dim3(kThreads), 0, st, out, n, seed);
+    hipLaunchKernelGGL(k_randn, dim3((unsigned)blocks), dim3(kThreads), 0, st, out, n, seed, offset);
     GL_HIP_CHECK(hipGetLastError());
     return 0;
 }

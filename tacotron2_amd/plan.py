@@ -141,11 +141,20 @@ class Plan:
                                         int(iterations), B, T, _stream_ptr(self.device)), "gl_run")
         return out
 
-    def randn(self, shape, seed):
+    def randn(self, shape, seed, offset=0):
+        """Standard normals from the device Philox stream of `seed`, starting at element `offset`."""
         out = torch.empty(shape, dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
-            _lib.check(self._lib.gl_randn(self._f32(out), out.numel(), ctypes.c_uint64(int(seed) & (2**64 - 1)),
-                                          _stream_ptr(self.device)), "gl_randn")
+            _lib.check(self._lib.gl_randn_at(self._f32(out), out.numel(), ctypes.c_uint64(int(seed) & (2**64 - 1)),
+                                             int(offset), _stream_ptr(self.device)), "gl_randn_at")
+        return out
+
+    def stitch_add(self, out, piece, offset, fade_in=0, fade_out=0):
+        """out (L,) += faded piece placed at sample `offset` (gl_stitch_add, long-form seams)."""
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.gl_stitch_add(self._f32(out), out.numel(), self._f32(piece), piece.numel(),
+                                               int(offset), int(fade_in), int(fade_out),
+                                               _stream_ptr(self.device)), "gl_stitch_add")
         return out
 
     def peak_normalise(self, x, mode=0):

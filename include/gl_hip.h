@@ -28,6 +28,7 @@ extern "C" {
 #endif
 
 typedef struct gl_plan gl_plan;
+typedef struct gl_graph gl_graph;
 
 enum gl_status {
     GL_OK = 0,
@@ -113,6 +114,21 @@ int gl_plan_set_path(gl_plan* plan, int path);
  * per-GPU shards vs. one big batch -- must be bit-identical.  Values below ceil((N-H)/H) are
  * raised to it.  No counterpart in the reference (a property of the GPU work split).          */
 int gl_plan_set_run_frames(gl_plan* plan, int frames);
+
+/* north_star (d): "the full N-iteration loop kept on-device on one HIP stream, and optionally
+ * hipGraph-captured".  The reference has no counterpart (its loop is a Python while,
+ * audio_utilities.py:178).  gl_plan_prepare makes every lazy allocation / table upload that gl_run
+ * (and gl_stft / gl_istft) of this plan could need, so that later calls only enqueue kernels and
+ * are legal inside a stream capture.  gl_graph_begin starts capturing `stream` (non-default,
+ * relaxed mode); every gl_* call enqueued on it until gl_graph_end becomes a node of the
+ * graph instead of running; gl_graph_end instantiates it.  gl_graph_launch replays the whole
+ * sequence (e.g. gl_mel_to_mag + gl_run(60) + gl_peak_normalise = 64 kernels) with one submission,
+ * on the same buffers it was captured with.  Plan settings (path, run length) are frozen in.       */
+int gl_plan_prepare(gl_plan* plan);
+int gl_graph_begin(void* stream);
+int gl_graph_end(void* stream, gl_graph** out);
+int gl_graph_launch(gl_graph* graph, void* stream);
+int gl_graph_destroy(gl_graph* graph);
 
 /* Device standard-normal fill (Philox4x32-10 + Box-Muller), for throughput runs
  * where bit-parity with numpy's MT19937 stream (audio_utilities.py:176) is not

@@ -34,6 +34,11 @@ SIGNATURES = {
                                         ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "gl_run": (ctypes.c_int, [_plan_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                               ctypes.c_void_p]),
+    "gl_plan_prepare": (ctypes.c_int, [_plan_p]),
+    "gl_graph_begin": (ctypes.c_int, [ctypes.c_void_p]),
+    "gl_graph_end": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]),
+    "gl_graph_launch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "gl_graph_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "gl_randn": (ctypes.c_int, [_c_float_p, ctypes.c_longlong, ctypes.c_uint64, ctypes.c_void_p]),
     "gl_randn_at": (ctypes.c_int, [_c_float_p, ctypes.c_longlong, ctypes.c_uint64, ctypes.c_longlong, ctypes.c_void_p]),
     "gl_stitch_add": (ctypes.c_int, [_c_float_p, ctypes.c_longlong, _c_float_p, ctypes.c_longlong, ctypes.c_longlong,

@@ -205,6 +205,58 @@ int gl_run(gl_plan* p, const float* mag, const float* x0, float* x_out, int iter
                        : gl_generic_run(p, mag, x0, x_out, iters, B, T, st);
 }
 
+int gl_plan_prepare(gl_plan* p) {
+    if (!p) return gl_set_error(GL_ERR_INVALID, "gl_plan_prepare: plan is NULL");
+    DeviceGuard guard(p->device);
+    return use_fast(p, GL_FAST_OP_RUN) ? gl_fast_prepare(p) : gl_generic_prepare(p);
+}
+
+struct gl_graph {
+    hipGraphExec_t exec;
+    int device;
+};
+
+int gl_graph_begin(void* stream) {
+    if (!stream) return gl_set_error(GL_ERR_INVALID, "gl_graph_begin: capture needs a non-default stream");
+    GL_HIP_CHECK(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeRelaxed));
+    return 0;
+}
+
+int gl_graph_end(void* stream, gl_graph** out) {
+    if (!stream || !out) return gl_set_error(GL_ERR_INVALID, "gl_graph_end: NULL argument");
+    *out = nullptr;
+    hipGraph_t graph = nullptr;
+    GL_HIP_CHECK(hipStreamEndCapture((hipStream_t)stream, &graph));
+    if (!graph) return gl_set_error(GL_ERR_HIP, "gl_graph_end: the capture was invalidated");
+    hipGraphExec_t exec = nullptr;
+    hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) return gl_set_error(GL_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+    gl_graph* g = new (std::nothrow) gl_graph();
+    if (!g) {
+        (void)hipGraphExecDestroy(exec);
+        return gl_set_error(GL_ERR_NOMEM, "host allocation failed");
+    }
+    g->exec = exec;
+    g->device = -1;
+    (void)hipGetDevice(&g->device);
+    *out = g;
+    return 0;
+}
+
+int gl_graph_launch(gl_graph* g, void* stream) {
+    if (!g) return gl_set_error(GL_ERR_INVALID, "gl_graph_launch: graph is NULL");
+    GL_HIP_CHECK(hipGraphLaunch(g->exec, (hipStream_t)stream));
+    return 0;
+}
+
+int gl_graph_destroy(gl_graph* g) {
+    if (!g) return 0;
+    (void)hipGraphExecDestroy(g->exec);
+    delete g;
+    return 0;
+}
+
 int gl_randn(float* out, long long n, uint64_t seed, void* stream) {
     if (!out || n < 0) return gl_set_error(GL_ERR_INVALID, "gl_randn: bad argument");
     if (n == 0) return 0;

@@ -1301,6 +1301,20 @@ bool gl_fast_supported(const gl_plan* p, int op) {
     return false;
 }
 
+// every lazy allocation / table upload gl_fast_run could need, so that a later call only enqueues
+int gl_fast_prepare(gl_plan* p) {
+    int rc = ensure_buffers(p);
+    if (rc) return rc;
+    if (p->n_fft == kN1) return ensure_table2(p);
+    rc = ensure_table(p);
+    if (!rc && p->hop % 128 == 0) {
+        rc = ensure_table2(p);
+        if (!rc && !p->d_magp)
+            rc = gl_plan_alloc(p, (void**)&p->d_magp, (size_t)p->max_B * p->max_T * kMagPack * sizeof(float));
+    }
+    return rc;
+}
+
 int gl_fast_stft(gl_plan* p, const float* x, long long x_stride, float* S, int B, int T, hipStream_t st) {
     int rc = ensure_table(p);
     if (rc) return rc;

@@ -198,6 +198,11 @@ int ensure_pingpong(gl_plan* p) {
 
 }  // namespace
 
+int gl_generic_prepare(gl_plan* p) {
+    int rc = ensure_frames(p);
+    return rc ? rc : ensure_pingpong(p);
+}
+
 int gl_generic_stft(gl_plan* p, const float* x, long long x_stride, float* S, int B, int T, hipStream_t st) {
     const int N = p->n_fft;
     size_t lds = (size_t)N * sizeof(float2);  // 2 * M complex

@@ -48,9 +48,12 @@ int gl_generic_istft(gl_plan* p, const float* S, float* y, int B, int T, hipStre
 int gl_generic_run(gl_plan* p, const float* mag, const float* x0, float* x_out, int iters, int B, int T,
                    hipStream_t st);
 
+int gl_generic_prepare(gl_plan* p);
+
 // ---- fused wave-per-frame kernels: gl_fast.hip -----------------------------------
 enum { GL_FAST_OP_STFT = 0, GL_FAST_OP_ISTFT = 1, GL_FAST_OP_RUN = 2 };
 bool gl_fast_supported(const gl_plan* p, int op);
+int gl_fast_prepare(gl_plan* p);
 int gl_fast_stft(gl_plan* p, const float* x, long long x_stride, float* S, int B, int T, hipStream_t st);
 int gl_fast_istft(gl_plan* p, const float* S, float* y, int B, int T, hipStream_t st);
 int gl_fast_run(gl_plan* p, const float* mag, const float* x0, float* x_out, int iters, int B, int T,

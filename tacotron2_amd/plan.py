@@ -157,10 +157,12 @@ class Plan:
                                                _stream_ptr(self.device)), "gl_stitch_add")
         return out
 
-    def peak_normalise(self, x, mode=0):
-        """In place on x (B, L); returns the per-row peaks (B,) before scaling."""
+    def peak_normalise(self, x, mode=0, peaks=None):
+        """In place on x (B, L); returns the per-row peaks (B,) before scaling (written into
+        `peaks` when given -- pass it under capture(), where nothing may be allocated)."""
         B, L = x.shape
-        peaks = torch.empty((B,), dtype=torch.float32, device=self.device)
+        if peaks is None:
+            peaks = torch.empty((B,), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             _lib.check(self._lib.gl_peak_normalise(self._h, self._f32(x), L, L, self._f32(peaks), int(mode), B,
                                                    _stream_ptr(self.device)), "gl_peak_normalise")
@@ -177,6 +179,73 @@ class Plan:
             _lib.check(self._lib.gl_pcm16_encode(self._h, self._f32(x), L, L, ctypes.c_void_p(pcm.data_ptr()), L,
                                                  self._f32(peaks), B, _stream_ptr(self.device)), "gl_pcm16_encode")
         return pcm, peaks
+
+
+    # -- hipGraph capture ---------------------------------------------------------------
+    def prepare(self):
+        """Make every lazy allocation of the Griffin-Lim path now (needed before capture())."""
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.gl_plan_prepare(self._h), "gl_plan_prepare")
+
+    def capture(self):
+        """Context manager: the plan calls made inside are recorded into a hipGraph instead of
+        running (all tensors, outputs included, must exist beforehand: pass out=...).
+
+            with plan.capture() as g:
+                plan.mel_to_mag(fb, mel, out=mag); plan.run(mag, x0, 60, out=x); plan.peak_normalise(x)
+            g.launch()          # replays the 64 kernels with one submission on the current stream
+        """
+        return _Capture(self)
+
+
+class Graph:
+    """An instantiated hipGraph of plan calls (gl_graph_*)."""
+
+    def __init__(self, lib, handle, device):
+        self._lib, self._h, self.device = lib, handle, device
+
+    def launch(self):
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.gl_graph_launch(self._h, _stream_ptr(self.device)), "gl_graph_launch")
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            self._lib.gl_graph_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _Capture:
+    def __init__(self, plan):
+        self.plan = plan
+        self.graph = Graph(plan._lib, ctypes.c_void_p(), plan.device)
+
+    def __enter__(self):
+        p = self.plan
+        p.prepare()
+        self._side = torch.cuda.Stream(device=p.device)
+        self._side.wait_stream(torch.cuda.current_stream(p.device))
+        self._ctx = torch.cuda.stream(self._side)
+        self._ctx.__enter__()
+        _lib.check(p._lib.gl_graph_begin(ctypes.c_void_p(self._side.cuda_stream)), "gl_graph_begin")
+        return self.graph
+
+    def __exit__(self, et, ev, tb):
+        p = self.plan
+        h = ctypes.c_void_p()
+        rc = p._lib.gl_graph_end(ctypes.c_void_p(self._side.cuda_stream), ctypes.byref(h))
+        self._ctx.__exit__(et, ev, tb)
+        if et is None:
+            _lib.check(rc, "gl_graph_end")
+            self.graph._h = h
+        elif rc == 0:
+            p._lib.gl_graph_destroy(h)
+        return False
 
 
 _cache = {}

@@ -418,3 +418,44 @@ def test_infer_glue_batch(golden, tmp_path, monkeypatch):
     # a single (T, n_mels) utterance is written as Inference.wav like infer.py:29
     one = griffin_lim.infer_to_wav(d["logmel"][0], iterations=2, seed=3)
     assert one[0].endswith("Inference.wav")
+
+
+@pytest.mark.gpu
+def test_hipgraph_replay_equals_stream_launch():
+    """north_star (d): mel->mag + the whole Griffin-Lim loop + peak normalise captured once
+    (gl_graph_begin/end) and replayed (gl_graph_launch) give the stream-launched bits, also after
+    the inputs change in place (the graph reads the same buffers)."""
+    from tacotron2_amd import filters
+    from tacotron2_amd.plan import Plan
+    N, H, T, B, K = 2048, 256, 120, 3, 7
+    dev = torch.device("cuda:0")
+    plan = Plan(N, H, T, B, dev)
+    rng = np.random.default_rng(31)
+    fb = torch.from_numpy(filters.mel(22050, N, 80, 125, 7600)).to(dev)
+    mel = torch.from_numpy(np.exp(rng.normal(-2, 1, (B, 80, T))).astype(np.float32)).to(dev)
+    x0 = torch.from_numpy(rng.standard_normal((B, T * H + N)).astype(np.float32)).to(dev)
+    mag = torch.empty((B, T, N // 2 + 1), device=dev)
+    x = torch.empty_like(x0)
+    peaks = torch.empty((B,), device=dev)
+
+    def eager():
+        m = plan.mel_to_mag(fb, mel)
+        y = plan.run(m, x0, K)
+        pk = plan.peak_normalise(y, mode=0)
+        return y.clone(), pk.clone()
+
+    with plan.capture() as g:
+        plan.mel_to_mag(fb, mel, out=mag)
+        plan.run(mag, x0, K, out=x)
+        plan.peak_normalise(x, mode=0, peaks=peaks)
+    x.zero_()
+    g.launch()
+    y_ref, pk_ref = eager()
+    assert torch.equal(x, y_ref) and torch.equal(peaks, pk_ref)
+    mel.mul_(0.5)
+    x0.copy_(torch.from_numpy(rng.standard_normal(tuple(x0.shape)).astype(np.float32)))
+    g.launch()
+    y_ref, pk_ref = eager()
+    assert torch.equal(x, y_ref) and torch.equal(peaks, pk_ref)
+    g.close()
+    plan.close()

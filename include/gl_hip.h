@@ -107,6 +107,20 @@ int gl_run(gl_plan* plan, const float* mag, const float* x0, float* x_out,
  * 1 = force the generic (any power-of-two N) kernels.  For tests/benchmarks.   */
 int gl_plan_set_path(gl_plan* plan, int path);
 
+/* Off-by-default variants the reference does not have (north_star names the first two):
+ *   GL_OPT_WSUM_NORMALISE  every inverse STFT -- inside gl_run and in gl_istft -- divides sample s by
+ *                          sum_t w^2(s - tH) (least-squares ISTFT of Griffin & Lim 1984; the reference's
+ *                          audio_utilities.py:108-114 leaves the sum in, gain ~ 0.375 N/H).  Samples no
+ *                          frame reaches are left as they are.
+ *   GL_OPT_CLAMP_MAG       gl_mel_to_mag / gl_logmel_to_mag write max(0, .): a pseudo-inverse basis
+ *                          (instead of griffin_lim.py:18's filterbank.T) produces negative magnitudes.
+ *   momentum in [0, 1)     fast Griffin-Lim (Perraudin, Balazs, Sondergaard 2013): the next iteration
+ *                          starts from x_n + momentum * (x_n - x_{n-1}); 0 = the reference's plain loop.
+ * With flags == 0 and momentum == 0 (the default) every entry point computes exactly what the reference
+ * does.  The variants cost one extra streaming pass over x per iteration.                            */
+enum { GL_OPT_WSUM_NORMALISE = 1, GL_OPT_CLAMP_MAG = 2 };
+int gl_plan_set_options(gl_plan* plan, int flags, float momentum);
+
 /* Frames each wavefront of the fused kernels processes in one run (0 = automatic: chosen from
  * B, T and the CU count to fill the GPU in whole rounds).  Results are bit-reproducible for a
  * given run length; overlap-add sums at run seams associate differently for different run

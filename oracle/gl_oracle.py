@@ -132,6 +132,40 @@ def griffin_lim_vec(mag, fft_size, hopsamp, iterations, x0):
     return x
 
 
+# --------------------------------------------------------------------------
+# Variants the reference does NOT have.  PARITY UNPINNED: there is no
+# reference code or fixture for them; these are float64 statements of the textbook
+# algorithms (Griffin & Lim 1984 least-squares ISTFT; Perraudin et al. 2013 fast
+# Griffin-Lim written in the signal domain) used to check the HIP options.
+# --------------------------------------------------------------------------
+def window_sum(n_frames, fft_size, hopsamp):
+    w2 = np.hanning(int(fft_size)) ** 2
+    acc = np.zeros(int(n_frames) * int(hopsamp) + int(fft_size))
+    for n in range(int(n_frames)):
+        acc[n * hopsamp:n * hopsamp + fft_size] += w2
+    return acc
+
+
+def istft_vec_normalised(X, fft_size, hopsamp):
+    y = istft_vec(X, fft_size, hopsamp)
+    ws = window_sum(X.shape[0], fft_size, hopsamp)
+    return np.where(ws > 1e-20, y / np.where(ws > 1e-20, ws, 1.0), y)
+
+
+def griffin_lim_variant(mag, fft_size, hopsamp, iterations, x0, normalize=False, momentum=0.0):
+    inv = istft_vec_normalised if normalize else istft_vec
+    t = np.asarray(x0, dtype=np.float64)
+    prev = None
+    for it in range(int(iterations)):
+        v = inv(project(stft_vec(t, fft_size, hopsamp), mag), fft_size, hopsamp)
+        if momentum and prev is not None and it != iterations - 1:
+            t = v + momentum * (v - prev)
+        else:
+            t = v
+        prev = v
+    return t
+
+
 def spectral_convergence(x, mag, fft_size, hopsamp, fit_gain=True):
     """|| |STFT(x)|/c - mag ||_F / || mag ||_F  (SURVEY 8d parity gate).  The
     reference ISTFT applies no window-sum normalisation, so x carries a gain of

@@ -25,6 +25,7 @@ SIGNATURES = {
     "gl_plan_device_bytes": (ctypes.c_longlong, [_plan_p]),
     "gl_plan_set_path": (ctypes.c_int, [_plan_p, ctypes.c_int]),
     "gl_plan_set_run_frames": (ctypes.c_int, [_plan_p, ctypes.c_int]),
+    "gl_plan_set_options": (ctypes.c_int, [_plan_p, ctypes.c_int, ctypes.c_float]),
     "gl_stft": (ctypes.c_int, [_plan_p, _c_float_p, ctypes.c_longlong, _c_float_p, ctypes.c_int, ctypes.c_int,
                                ctypes.c_void_p]),
     "gl_istft": (ctypes.c_int, [_plan_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),

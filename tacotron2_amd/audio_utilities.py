@@ -121,10 +121,11 @@ def stft_for_reconstruction(x, fft_size, hopsamp, *, device=None):
 
 
 # -- a-5 ---------------------------------------------------------------------------------------
-def istft_for_reconstruction(X, fft_size, hopsamp, *, device=None):
+def istft_for_reconstruction(X, fft_size, hopsamp, *, normalize=False, device=None):
     """Inverse STFT by windowed overlap-add without window-sum normalisation
     (audio_utilities.py:95-114).  X: (T, F) or (B, T, F) complex.
-    Returns (T*hopsamp + fft_size,) [or (B, ...)]."""
+    Returns (T*hopsamp + fft_size,) [or (B, ...)].  normalize=True (not the reference) divides by
+    the overlap-added squared window."""
     fft_size, hopsamp = int(fft_size), int(hopsamp)
     dev = _pick_device(device, X)
     Xt, was_np = _to_device(X, dev, torch.complex64)
@@ -140,7 +141,7 @@ def istft_for_reconstruction(X, fft_size, hopsamp, *, device=None):
         y = torch.zeros((B, fft_size), dtype=torch.float32, device=dev)
     else:
         plan = get_plan(fft_size, hopsamp, T, B, dev)
-        y = plan.istft(Xt)
+        y = plan.istft(Xt, normalize=normalize)
     if single:
         y = y[0]
     if was_np:
@@ -169,12 +170,15 @@ def _start_signal(B, L, x_init, seed, rng, plan, dev):
 
 
 def reconstruct_signal_griffin_lim(magnitude_spectrogram, fft_size, hopsamp, iterations, *,
-                                   x_init=None, seed=None, rng="numpy", device=None):
+                                   x_init=None, seed=None, rng="numpy", device=None, normalize=False,
+                                   momentum=0.0):
     """Griffin-Lim reconstruction (audio_utilities.py:154-188).
 
     magnitude_spectrogram: (T, F) or (B, T, F), rows = time slices.  The whole
     loop (STFT -> keep phase, impose magnitude -> ISTFT) runs on the GPU on the
-    current HIP stream.  Returns (T*hopsamp + fft_size,) [or (B, ...)]."""
+    current HIP stream.  Returns (T*hopsamp + fft_size,) [or (B, ...)].
+    normalize / momentum (both off = the reference): window-sum normalised inverse STFT in every
+    iteration; fast Griffin-Lim extrapolation x_n + momentum (x_n - x_{n-1})."""
     fft_size, hopsamp, iterations = int(fft_size), int(hopsamp), int(iterations)
     dev = _pick_device(device, magnitude_spectrogram, x_init)
     mag, was_np = _to_device(magnitude_spectrogram, dev, torch.float32)
@@ -191,7 +195,7 @@ def reconstruct_signal_griffin_lim(magnitude_spectrogram, fft_size, hopsamp, ite
     L = T * hopsamp + fft_size
     plan = get_plan(fft_size, hopsamp, T, B, dev)
     x0 = _start_signal(B, L, x_init, seed, rng, plan, dev)
-    x = plan.run(mag, x0, iterations, out=x0)
+    x = plan.run(mag, x0, iterations, out=x0, normalize=normalize, momentum=momentum)
     if single:
         x = x[0]
     if was_np:

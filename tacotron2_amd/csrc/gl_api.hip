@@ -50,6 +50,37 @@ int gl_plan_alloc(gl_plan* p, void** ptr, size_t bytes) {
     return 0;
 }
 
+int gl_ensure_options(gl_plan* p, int T) {
+    const int N = p->n_fft, H = p->hop;
+    if (p->momentum != 0.0f && !p->d_prev) {
+        int rc = gl_plan_alloc(p, (void**)&p->d_prev, (size_t)p->max_B * gl_len(N, H, p->max_T) * sizeof(float));
+        if (rc) return rc;
+    }
+    if ((p->opt_flags & GL_OPT_WSUM_NORMALISE) && p->wsum_T != T) {
+        if (!p->d_inv_wsum) {
+            int rc = gl_plan_alloc(p, (void**)&p->d_inv_wsum, (size_t)gl_len(N, H, p->max_T) * sizeof(float));
+            if (rc) return rc;
+        }
+        // sum over the frames covering s of w^2 (double on the host); samples no frame reaches, or
+        // where the sum underflows, are left unscaled (the convention of librosa's istft)
+        const long long L = gl_len(N, H, T);
+        const double pi = 3.14159265358979323846;
+        std::vector<double> w2(N);
+        for (int n = 0; n < N; ++n) {
+            double w = 0.5 - 0.5 * cos(2.0 * pi * n / (double)(N - 1));
+            w2[n] = w * w;
+        }
+        std::vector<double> acc((size_t)L, 0.0);
+        for (int t = 0; t < T; ++t)
+            for (int n = 0; n < N; ++n) acc[(size_t)t * H + n] += w2[n];
+        std::vector<float> inv((size_t)L);
+        for (long long s2 = 0; s2 < L; ++s2) inv[(size_t)s2] = acc[(size_t)s2] > 1e-20 ? (float)(1.0 / acc[(size_t)s2]) : 1.0f;
+        GL_HIP_CHECK(hipMemcpy(p->d_inv_wsum, inv.data(), (size_t)L * sizeof(float), hipMemcpyHostToDevice));
+        p->wsum_T = T;
+    }
+    return 0;
+}
+
 extern "C" {
 
 int gl_version(void) { return 100; }
@@ -120,7 +151,8 @@ int gl_plan_destroy(gl_plan* p) {
     if (!p) return 0;
     DeviceGuard guard(p->device);
     void* ptrs[] = {p->d_window, p->d_tw,     p->d_frames, p->d_xa,      p->d_xb,
-                    p->d_tail_a, p->d_tail_b, p->d_fast_tab, p->d_peaks, p->d_fast_tab2, p->d_magp};
+                    p->d_tail_a, p->d_tail_b, p->d_fast_tab, p->d_peaks, p->d_fast_tab2, p->d_magp,
+                    p->d_inv_wsum, p->d_prev};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     delete p;
@@ -138,6 +170,16 @@ int gl_plan_set_path(gl_plan* p, int path) {
 int gl_plan_set_run_frames(gl_plan* p, int frames) {
     if (!p || frames < 0) return gl_set_error(GL_ERR_INVALID, "gl_plan_set_run_frames: bad argument");
     p->run_frames = frames;
+    return 0;
+}
+
+int gl_plan_set_options(gl_plan* p, int flags, float momentum) {
+    if (!p || (flags & ~(GL_OPT_WSUM_NORMALISE | GL_OPT_CLAMP_MAG)) != 0)
+        return gl_set_error(GL_ERR_INVALID, "gl_plan_set_options: bad argument");
+    if (!(momentum >= 0.0f && momentum < 1.0f))
+        return gl_set_error(GL_ERR_INVALID, "gl_plan_set_options: momentum must be in [0, 1), got %g", (double)momentum);
+    p->opt_flags = flags;
+    p->momentum = momentum;
     return 0;
 }
 
@@ -167,7 +209,10 @@ int gl_istft(gl_plan* p, const float* S, float* y, int B, int T, void* stream) {
     if (!S || !y) return gl_set_error(GL_ERR_INVALID, "gl_istft: NULL buffer");
     DeviceGuard guard(p->device);
     hipStream_t st = (hipStream_t)stream;
-    return use_fast(p, GL_FAST_OP_ISTFT) ? gl_fast_istft(p, S, y, B, T, st) : gl_generic_istft(p, S, y, B, T, st);
+    rc = use_fast(p, GL_FAST_OP_ISTFT) ? gl_fast_istft(p, S, y, B, T, st) : gl_generic_istft(p, S, y, B, T, st);
+    if (rc || !(p->opt_flags & GL_OPT_WSUM_NORMALISE)) return rc;
+    rc = gl_ensure_options(p, T);
+    return rc ? rc : gl_post_iter(p, y, nullptr, y, B, T, 1, 1, true, true, st);
 }
 
 int gl_mel_to_mag(gl_plan* p, const float* filterbank, const float* mel, float* mag, int n_mels, int B, int T,
@@ -177,7 +222,8 @@ int gl_mel_to_mag(gl_plan* p, const float* filterbank, const float* mel, float* 
     if (!filterbank || !mel || !mag) return gl_set_error(GL_ERR_INVALID, "gl_mel_to_mag: NULL buffer");
     if (n_mels < 1 || n_mels > 4096) return gl_set_error(GL_ERR_INVALID, "gl_mel_to_mag: n_mels=%d", n_mels);
     DeviceGuard guard(p->device);
-    return gl_mel_launch(filterbank, mel, mag, n_mels, p->n_fft / 2 + 1, B, T, false, 1.0f, (hipStream_t)stream);
+    return gl_mel_launch(filterbank, mel, mag, n_mels, p->n_fft / 2 + 1, B, T, false, 1.0f,
+                         (p->opt_flags & GL_OPT_CLAMP_MAG) != 0, (hipStream_t)stream);
 }
 
 int gl_logmel_to_mag(gl_plan* p, const float* filterbank, const float* logmel, float* mag, int n_mels,
@@ -190,7 +236,7 @@ int gl_logmel_to_mag(gl_plan* p, const float* filterbank, const float* logmel, f
         return gl_set_error(GL_ERR_INVALID, "gl_logmel_to_mag: compression_factor must be > 0");
     DeviceGuard guard(p->device);
     return gl_mel_launch(filterbank, logmel, mag, n_mels, p->n_fft / 2 + 1, B, T, true, compression_factor,
-                         (hipStream_t)stream);
+                         (p->opt_flags & GL_OPT_CLAMP_MAG) != 0, (hipStream_t)stream);
 }
 
 int gl_run(gl_plan* p, const float* mag, const float* x0, float* x_out, int iters, int B, int T, void* stream) {
@@ -201,6 +247,10 @@ int gl_run(gl_plan* p, const float* mag, const float* x0, float* x_out, int iter
     DeviceGuard guard(p->device);
     hipStream_t st = (hipStream_t)stream;
     if (iters == 0) return gl_copy_rows(x_out, x0, (long long)B * gl_len(p->n_fft, p->hop, T), st);
+    if (gl_post_needed(p)) {
+        rc = gl_ensure_options(p, T);
+        if (rc) return rc;
+    }
     return use_fast(p, GL_FAST_OP_RUN) ? gl_fast_run(p, mag, x0, x_out, iters, B, T, st)
                        : gl_generic_run(p, mag, x0, x_out, iters, B, T, st);
 }
@@ -208,6 +258,8 @@ int gl_run(gl_plan* p, const float* mag, const float* x0, float* x_out, int iter
 int gl_plan_prepare(gl_plan* p) {
     if (!p) return gl_set_error(GL_ERR_INVALID, "gl_plan_prepare: plan is NULL");
     DeviceGuard guard(p->device);
+    int rc = gl_post_needed(p) ? gl_ensure_options(p, p->max_T) : 0;
+    if (rc) return rc;
     return use_fast(p, GL_FAST_OP_RUN) ? gl_fast_prepare(p) : gl_generic_prepare(p);
 }
 

@@ -1043,6 +1043,28 @@ __global__ void __launch_bounds__(256) k_fold_tails(const float* __restrict__ x_
         fetch_x(x_main + (long long)b * L, tail + (long long)b * nruns * ovl, s, g_h, nruns, ovl);
 }
 
+// Post pass of the optional (non-reference) variants, one launch per iteration when enabled:
+// v = x_main[s] + tail; window-sum normalisation v *= inv_wsum[s]; fast Griffin-Lim momentum
+// t = v + alpha (v - prev[s]), prev[s] = v (Perraudin et al. 2013, in the signal domain: the STFT
+// is linear, so extrapolating the signals extrapolates the consistent spectrograms).  The first
+// iteration has no predecessor and the last one returns v itself.
+__global__ void __launch_bounds__(256) k_post_iter(const float* __restrict__ x_main, const float* __restrict__ tail,
+                                                   const float* __restrict__ inv_wsum, float* __restrict__ prev,
+                                                   float* __restrict__ out, long long L, int g_h, int nruns, int ovl,
+                                                   float alpha, int first, int last) {
+    const int b = blockIdx.y;
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= L) return;
+    float v = fetch_x(x_main + (long long)b * L, tail ? tail + (long long)b * nruns * ovl : nullptr, s, g_h, nruns, ovl);
+    if (inv_wsum) v *= inv_wsum[s];
+    float t = v;
+    if (prev) {
+        if (!first && !last) t = v + alpha * (v - prev[(long long)b * L + s]);
+        if (!last) prev[(long long)b * L + s] = v;
+    }
+    out[(long long)b * L + s] = t;
+}
+
 // Frames per wave-run.  A run costs its frames plus a fixed prologue/epilogue (ring fill,
 // tail write, ~1.5 frame-times); the launch finishes after ceil(runs / resident waves)
 // rounds, so choose the G that minimises rounds * (G + overhead).  G*H >= N-H keeps the
@@ -1223,6 +1245,7 @@ int run_regring(gl_plan* p, const float* mag, const float* x0, float* x_out, int
     a.L = gl_len(p->n_fft, p->hop, T);
     const float* src = x0;
     const float* src_tail = nullptr;
+    const bool post = gl_post_needed(p);
     for (int it = 0; it < iters; ++it) {
         const bool last = (it == iters - 1);
         float* dst = (it & 1) ? p->d_xb : p->d_xa;
@@ -1236,6 +1259,13 @@ int run_regring(gl_plan* p, const float* mag, const float* x0, float* x_out, int
         if (rc) return rc;
         src = dst;
         src_tail = (nruns > 1) ? dst_tail : nullptr;
+        if (post) {      // optional variants: complete the signal now and transform it
+            float* o = last ? x_out : dst;
+            rc = gl_post_iter(p, dst, src_tail, o, B, T, G, nruns, it == 0, last, st);
+            if (rc) return rc;
+            src = o;
+            src_tail = nullptr;
+        }
     }
 #ifdef GL_STAMPS
     {
@@ -1251,7 +1281,7 @@ int run_regring(gl_plan* p, const float* mag, const float* x0, float* x_out, int
         GL_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), h, sizeof(h)));
     }
 #endif
-    if (nruns > 1) return fold(p, src, src_tail, x_out, B, T, G, nruns, st);
+    if (nruns > 1 && !post) return fold(p, src, src_tail, x_out, B, T, G, nruns, st);
     return 0;
 }
 
@@ -1274,6 +1304,7 @@ int run_pair1024(gl_plan* p, const float* mag, const float* x0, float* x_out, in
     dim3 grid((nruns + kP1Waves - 1) / kP1Waves, B);
     const float* src = x0;
     const float* src_tail = nullptr;
+    const bool post = gl_post_needed(p);
     for (int it = 0; it < iters; ++it) {
         const bool last = (it == iters - 1);
         float* dst = (it & 1) ? p->d_xb : p->d_xa;
@@ -1287,12 +1318,31 @@ int run_pair1024(gl_plan* p, const float* mag, const float* x0, float* x_out, in
         GL_HIP_CHECK(hipGetLastError());
         src = dst;
         src_tail = (nruns > 1) ? dst_tail : nullptr;
+        if (post) {      // optional variants: complete the signal now and transform it
+            float* o = last ? x_out : dst;
+            rc = gl_post_iter(p, dst, src_tail, o, B, T, G, nruns, it == 0, last, st);
+            if (rc) return rc;
+            src = o;
+            src_tail = nullptr;
+        }
     }
-    if (nruns > 1) return fold(p, src, src_tail, x_out, B, T, G, nruns, st);
+    if (nruns > 1 && !post) return fold(p, src, src_tail, x_out, B, T, G, nruns, st);
     return 0;
 }
 
 }  // namespace
+
+int gl_post_iter(gl_plan* p, const float* x_main, const float* tail, float* out, int B, int T, int G, int nruns,
+                 bool first, bool last, hipStream_t st) {
+    const long long L = gl_len(p->n_fft, p->hop, T);
+    dim3 grid((unsigned)((L + 255) / 256), B);
+    hipLaunchKernelGGL(k_post_iter, grid, dim3(256), 0, st, x_main, tail,
+                       (p->opt_flags & GL_OPT_WSUM_NORMALISE) ? p->d_inv_wsum : nullptr,
+                       p->momentum != 0.0f ? p->d_prev : nullptr, out, L, G * p->hop, nruns, p->n_fft - p->hop,
+                       p->momentum, first ? 1 : 0, last ? 1 : 0);
+    GL_HIP_CHECK(hipGetLastError());
+    return 0;
+}
 
 bool gl_fast_supported(const gl_plan* p, int op) {
     if (p->hop < 1) return false;
@@ -1372,6 +1422,7 @@ int gl_fast_run(gl_plan* p, const float* mag, const float* x0, float* x_out, int
     a.nruns_in = nruns;
     const float* src = x0;
     const float* src_tail = nullptr;
+    const bool post = gl_post_needed(p);
     for (int it = 0; it < iters; ++it) {
         const bool last = (it == iters - 1);
         float* dst = (it & 1) ? p->d_xb : p->d_xa;
@@ -1386,7 +1437,14 @@ int gl_fast_run(gl_plan* p, const float* mag, const float* x0, float* x_out, int
         if (rc) return rc;
         src = dst;
         src_tail = (nruns > 1) ? dst_tail : nullptr;
+        if (post) {      // optional variants: complete the signal now and transform it
+            float* o = last ? x_out : dst;
+            rc = gl_post_iter(p, dst, src_tail, o, B, T, G, nruns, it == 0, last, st);
+            if (rc) return rc;
+            src = o;
+            src_tail = nullptr;
+        }
     }
-    if (nruns > 1) return fold(p, src, src_tail, x_out, B, T, G, nruns, st);
+    if (nruns > 1 && !post) return fold(p, src, src_tail, x_out, B, T, G, nruns, st);
     return 0;
 }

@@ -243,12 +243,14 @@ int gl_generic_run(gl_plan* p, const float* mag, const float* x0, float* x_out, 
     const long long L = gl_len(N, p->hop, T);
     size_t lds = (size_t)N * sizeof(float2);
     const float* src = x0;
+    const bool post = gl_post_needed(p);
     for (int it = 0; it < iters; ++it) {
         float* dst = (it == iters - 1) ? x_out : ((it & 1) ? p->d_xb : p->d_xa);
         hipLaunchKernelGGL(k_generic_gl_frame, dim3(T, B), dim3(kThreads), lds, st, src, L, mag, p->d_frames,
                            p->d_window, p->d_tw, N, p->hop, T);
         GL_HIP_CHECK(hipGetLastError());
         rc = launch_ola(p, dst, B, T, st);
+        if (!rc && post) rc = gl_post_iter(p, dst, nullptr, dst, B, T, 1, 1, it == 0, it == iters - 1, st);
         if (rc) return rc;
         src = dst;
     }

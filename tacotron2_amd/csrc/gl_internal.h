@@ -26,6 +26,11 @@ struct gl_plan {
     float* d_fast_tab2; // register-ring kernel constant table (lazy)
     float* d_magp;      // register-ring kernel: magnitudes repacked per lane [max_B][max_T][1088] (lazy)
     unsigned* d_peaks;  // [max_B] bit patterns of max|x|
+    int opt_flags;      // GL_OPT_* (gl_plan_set_options)
+    float momentum;     // fast Griffin-Lim extrapolation factor, 0 = off
+    float* d_inv_wsum;  // [L(wsum_T)] 1 / sum_t w^2(s - tH)  (lazy, rebuilt when T changes)
+    int wsum_T;
+    float* d_prev;      // [max_B][L] previous iterate for the momentum option (lazy)
     long long bytes;
 };
 
@@ -54,6 +59,14 @@ int gl_generic_prepare(gl_plan* p);
 enum { GL_FAST_OP_STFT = 0, GL_FAST_OP_ISTFT = 1, GL_FAST_OP_RUN = 2 };
 bool gl_fast_supported(const gl_plan* p, int op);
 int gl_fast_prepare(gl_plan* p);
+// per-iteration post pass of the off-by-default options (window-sum normalisation, momentum):
+// out[s] = f(x_main[s] + tail) ; tail == nullptr when x_main is already complete
+static inline bool gl_post_needed(const gl_plan* p) {
+    return (p->opt_flags & GL_OPT_WSUM_NORMALISE) != 0 || p->momentum != 0.0f;
+}
+int gl_post_iter(gl_plan* p, const float* x_main, const float* tail, float* out, int B, int T, int G, int nruns,
+                 bool first, bool last, hipStream_t st);
+int gl_ensure_options(gl_plan* p, int T);   // allocations / tables the options need for T frames
 int gl_fast_stft(gl_plan* p, const float* x, long long x_stride, float* S, int B, int T, hipStream_t st);
 int gl_fast_istft(gl_plan* p, const float* S, float* y, int B, int T, hipStream_t st);
 int gl_fast_run(gl_plan* p, const float* mag, const float* x0, float* x_out, int iters, int B, int T,
@@ -61,7 +74,7 @@ int gl_fast_run(gl_plan* p, const float* mag, const float* x0, float* x_out, int
 
 // ---- mel inversion (MFMA): gl_mel.hip ---------------------------------------------
 int gl_mel_launch(const float* fb, const float* mel, float* mag, int n_mels, int F, int B, int T, bool logmel,
-                  float compression_factor, hipStream_t st);
+                  float compression_factor, bool clamp, hipStream_t st);
 
 // ---- misc: gl_misc.hip -------------------------------------------------------------
 int gl_randn_launch(float* out, long long n, uint64_t seed, long long offset, hipStream_t st);

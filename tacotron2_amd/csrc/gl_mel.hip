@@ -29,7 +29,7 @@ template <bool LOGMEL>
 __global__ void __launch_bounds__(64 * kWaves) k_mel_to_mag(const float* __restrict__ fb,
                                                             const float* __restrict__ mel,
                                                             float* __restrict__ mag, int K, int F, int T,
-                                                            float inv_cf) {
+                                                            float inv_cf, float floor_val) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int b = blockIdx.z;
@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(64 * kWaves) k_mel_to_mag(const float* __restr
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = t0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            if (row < T) out[(long long)row * F + f] = acc[j][r];
+            if (row < T) out[(long long)row * F + f] = fmaxf(acc[j][r], floor_val);   // -inf: no clamp
         }
     }
 }
@@ -91,13 +91,15 @@ __global__ void __launch_bounds__(64 * kWaves) k_mel_to_mag(const float* __restr
 }  // namespace
 
 int gl_mel_launch(const float* fb, const float* mel, float* mag, int n_mels, int F, int B, int T, bool logmel,
-                  float compression_factor, hipStream_t st) {
+                  float compression_factor, bool clamp, hipStream_t st) {
+    const float floor_val = clamp ? 0.0f : -INFINITY;     // GL_OPT_CLAMP_MAG (pseudo-inverse bases go negative)
     dim3 grid((F + kTileF - 1) / kTileF, (T + kTileT * kWaves - 1) / (kTileT * kWaves), B);
     if (logmel)
         hipLaunchKernelGGL(k_mel_to_mag<true>, grid, dim3(64 * kWaves), 0, st, fb, mel, mag, n_mels, F, T,
-                           1.0f / compression_factor);
+                           1.0f / compression_factor, floor_val);
     else
-        hipLaunchKernelGGL(k_mel_to_mag<false>, grid, dim3(64 * kWaves), 0, st, fb, mel, mag, n_mels, F, T, 1.0f);
+        hipLaunchKernelGGL(k_mel_to_mag<false>, grid, dim3(64 * kWaves), 0, st, fb, mel, mag, n_mels, F, T, 1.0f,
+                           floor_val);
     GL_HIP_CHECK(hipGetLastError());
     return 0;
 }

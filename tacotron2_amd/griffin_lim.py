@@ -45,12 +45,14 @@ def _device_filterbank(fb, dev):
 
 
 def mel_to_audio(mel_spectrogram, *, basis=None, n_fft=None, hop=None, iterations=None, x_init=None, seed=None,
-                 rng="numpy", normalize="reference", device=None):
+                 rng="numpy", normalize="reference", device=None, window_sum_normalize=False, momentum=0.0):
     """Batched core of save_mel_to_wav, everything on the GPU.
 
     mel_spectrogram: (n_mels, T) or (B, n_mels, T), numpy or torch (linear-amplitude
     mel, i.e. after exp, infer.py:27).  basis: (F, n_mels) inversion basis; default
-    ``filterbank.T`` like griffin_lim.py:18.  normalize: 'reference' (divide by the
+    ``filterbank.T`` like griffin_lim.py:18; ``"pinv"`` = pseudo-inverse of the filterbank with the
+    magnitudes clamped at 0 (north-star variant, not the reference).  window_sum_normalize /
+    momentum: see audio_utilities.reconstruct_signal_griffin_lim.  normalize: 'reference' (divide by the
     peak only when it exceeds 1, griffin_lim.py:27-29), 'peak' (always) or None.
     Returns (waveforms (B, L) fp32 torch on device, magnitude (B, T, F) fp32 torch)."""
     n_fft = int(params.n_fft if n_fft is None else n_fft)
@@ -63,6 +65,13 @@ def mel_to_audio(mel_spectrogram, *, basis=None, n_fft=None, hop=None, iteration
     if mel.dim() != 3:
         raise ValueError("mel_spectrogram must be (n_mels, T) or (B, n_mels, T)")
     B, n_mels, T = mel.shape
+    clamp = isinstance(basis, str)
+    if clamp:
+        if basis != "pinv":
+            raise ValueError("basis must be an (F, n_mels) array, None or 'pinv'")
+        fb = filterbank if (n_fft == params.n_fft and n_mels == params.n_mel_channels) else filters.mel(
+            sr=params.sampling_rate, n_fft=n_fft, n_mels=n_mels, fmin=params.f_min, fmax=params.f_max)
+        basis = filters.pinv_basis(fb)
     if basis is None:
         if n_fft != params.n_fft:
             fb = filters.mel(sr=params.sampling_rate, n_fft=n_fft, n_mels=n_mels, fmin=params.f_min,
@@ -77,10 +86,10 @@ def mel_to_audio(mel_spectrogram, *, basis=None, n_fft=None, hop=None, iteration
         raise ValueError(f"basis/filterbank shape {tuple(fb_dev.shape)} does not match "
                          f"({n_mels}, {n_fft // 2 + 1})")
     plan = get_plan(n_fft, hop, T, B, dev)
-    mag = plan.mel_to_mag(fb_dev, mel)                       # griffin_lim.py:18-19
+    mag = plan.mel_to_mag(fb_dev, mel, clamp=clamp)          # griffin_lim.py:18-19
     L = plan.signal_length(T)
     x0 = audio_utilities._start_signal(B, L, x_init, seed, rng, plan, dev)
-    x = plan.run(mag, x0, iterations, out=x0)                # griffin_lim.py:23-24
+    x = plan.run(mag, x0, iterations, out=x0, normalize=window_sum_normalize, momentum=momentum)   # :23-24
     if normalize == "reference":
         plan.peak_normalise(x, mode=0)                       # griffin_lim.py:27-29
     elif normalize == "peak":

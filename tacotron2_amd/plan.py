@@ -70,6 +70,11 @@ class Plan:
         for different batch sizes (per-GPU shards vs one batch) must be bit-identical."""
         _lib.check(self._lib.gl_plan_set_run_frames(self._h, int(frames)), "gl_plan_set_run_frames")
 
+    def set_options(self, window_sum_normalize=False, clamp_mag=False, momentum=0.0):
+        """Off-by-default variants (gl_plan_set_options); the defaults are the reference's behaviour."""
+        flags = (1 if window_sum_normalize else 0) | (2 if clamp_mag else 0)
+        _lib.check(self._lib.gl_plan_set_options(self._h, flags, float(momentum)), "gl_plan_set_options")
+
     def _f32(self, t, shape=None):
         if t.device != self.device or t.dtype != torch.float32 or not t.is_contiguous():
             raise ValueError("expected a contiguous float32 tensor on %s" % (self.device,))
@@ -90,8 +95,9 @@ class Plan:
                                          _stream_ptr(self.device)), "gl_stft")
         return torch.view_as_complex(S)
 
-    def istft(self, S):
-        """complex64 (B, T, F) -> (B, T*H+N) fp32."""
+    def istft(self, S, normalize=False):
+        """complex64 (B, T, F) -> (B, T*H+N) fp32.  normalize: divide by the window-square sum."""
+        self.set_options(window_sum_normalize=normalize)
         if S.dtype != torch.complex64:
             raise ValueError("expected complex64")
         Sr = torch.view_as_real(S.contiguous())
@@ -104,8 +110,9 @@ class Plan:
                                           _stream_ptr(self.device)), "gl_istft")
         return y
 
-    def mel_to_mag(self, filterbank, mel, out=None):
-        """filterbank (n_mels, F), mel (B, n_mels, T) -> mag (B, T, F)."""
+    def mel_to_mag(self, filterbank, mel, out=None, clamp=False):
+        """filterbank (n_mels, F), mel (B, n_mels, T) -> mag (B, T, F).  clamp: max(0, .)."""
+        self.set_options(clamp_mag=clamp)
         B, n_mels, T = mel.shape
         if out is None:
             out = torch.empty((B, T, self.n_bins), dtype=torch.float32, device=self.device)
@@ -115,9 +122,10 @@ class Plan:
                                                _stream_ptr(self.device)), "gl_mel_to_mag")
         return out
 
-    def logmel_to_mag(self, filterbank, logmel, compression_factor=1.0, out=None):
+    def logmel_to_mag(self, filterbank, logmel, compression_factor=1.0, out=None, clamp=False):
         """filterbank (n_mels, F), logmel (B, T, n_mels) natural-log mel (the decoder's layout)
         -> mag (B, T, F); exp, 1/compression_factor and the transpose are fused (infer.py:27-28)."""
+        self.set_options(clamp_mag=clamp)
         B, T, n_mels = logmel.shape
         if out is None:
             out = torch.empty((B, T, self.n_bins), dtype=torch.float32, device=self.device)
@@ -128,8 +136,10 @@ class Plan:
                                                   _stream_ptr(self.device)), "gl_logmel_to_mag")
         return out
 
-    def run(self, mag, x0, iterations, out=None):
-        """mag (B, T, F), x0 (B, L) -> x (B, L) after `iterations` Griffin-Lim iterations."""
+    def run(self, mag, x0, iterations, out=None, normalize=False, momentum=0.0):
+        """mag (B, T, F), x0 (B, L) -> x (B, L) after `iterations` Griffin-Lim iterations.
+        normalize / momentum: window-sum normalised ISTFT, fast Griffin-Lim (not in the reference)."""
+        self.set_options(window_sum_normalize=normalize, momentum=momentum)
         B, T, F = mag.shape
         if F != self.n_bins:
             raise ValueError(f"expected {self.n_bins} bins, got {F}")

@@ -459,3 +459,54 @@ def test_hipgraph_replay_equals_stream_launch():
     assert torch.equal(x, y_ref) and torch.equal(peaks, pk_ref)
     g.close()
     plan.close()
+
+
+# ---- N4: variants the reference does not have (parity unpinned; float64 textbook statements) -----------
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,H,path", [(2048, 256, 0), (1024, 275, 0), (2048, 300, 0), (256, 100, 1)])
+@pytest.mark.parametrize("normalize,momentum", [(True, 0.0), (False, 0.5), (True, 0.99)])
+def test_variants_window_sum_normalisation_and_momentum(N, H, path, normalize, momentum):
+    from tacotron2_amd.plan import Plan
+    T, K, B = 90, 8, 2
+    F = N // 2 + 1
+    rng = np.random.default_rng(41)
+    u = rng.normal(-2.0, 1.0, size=(B, T, F))
+    u = (u + np.roll(u, 1, 1) + np.roll(u, -1, 1) + np.roll(u, 1, 2) + np.roll(u, -1, 2)) / 5.0
+    mag = np.exp(u).astype(np.float32)
+    x0 = rng.standard_normal((B, T * H + N)).astype(np.float32)
+    plan = Plan(N, H, T, B, "cuda:0")
+    plan.set_path(path)
+    x = plan.run(torch.from_numpy(mag).cuda(), torch.from_numpy(x0).cuda(), K, normalize=normalize,
+                 momentum=momentum).cpu().numpy()
+    plain = plan.run(torch.from_numpy(mag).cuda(), torch.from_numpy(x0).cuda(), K).cpu().numpy()
+    for b in range(B):
+        ref = orc.griffin_lim_variant(mag[b].astype(np.float64), N, H, K, x0[b].astype(np.float64), normalize, momentum)
+        # the normalised signal has 1/w^2-amplified samples at the very edges: compare on the body's scale
+        body = np.max(np.abs(ref[N:-N]))
+        assert np.max(np.abs(x[b] - ref)[N:-N]) <= 1e-3 * body
+        assert np.max(np.abs(x[b] - ref)) <= 1e-3 * np.max(np.abs(ref))
+        # and the default call is still the reference loop
+        ref0 = orc.griffin_lim_vec(mag[b].astype(np.float64), N, H, K, x0[b].astype(np.float64))
+        assert np.max(np.abs(plain[b] - ref0)) <= 1e-3 * np.max(np.abs(ref0))
+    plan.close()
+
+
+@pytest.mark.gpu
+def test_variant_istft_normalised_inverts_stft_and_pinv_basis_clamps():
+    from tacotron2_amd import audio_utilities as au, griffin_lim as glm, filters
+    N, H, T = 2048, 256, 40
+    rng = np.random.default_rng(43)
+    x = rng.standard_normal(T * H + N)
+    S = au.stft_for_reconstruction(x, N, H, device="cuda:0")
+    y = au.istft_for_reconstruction(S, N, H, normalize=True, device="cuda:0")
+    ref = orc.istft_vec_normalised(orc.stft_vec(x, N, H), N, H)
+    assert np.max(np.abs(y - ref)[N:-N]) <= 2e-5 * np.max(np.abs(ref[N:-N]))
+    assert np.max(np.abs(y - x)[N:-N]) <= 1e-4            # least-squares ISTFT of a consistent STFT is the signal
+    y0 = au.istft_for_reconstruction(S, N, H, device="cuda:0")       # default: reference, no normalisation
+    assert np.max(np.abs(y0 - orc.istft_vec(orc.stft_vec(x, N, H), N, H))) <= 2e-5 * np.max(np.abs(y0))
+    mel = np.exp(rng.normal(-2, 1, (80, T))).astype(np.float32)
+    fb = filters.mel(22050, N, 80, 125, 7600)
+    _, mag = glm.mel_to_audio(mel, basis="pinv", n_fft=N, hop=H, iterations=1, seed=1, device="cuda:0")
+    want = np.maximum(0.0, filters.pinv_basis(fb).astype(np.float64) @ mel.astype(np.float64)).T
+    assert np.max(np.abs(mag[0].cpu().numpy() - want)) <= 1e-5 * np.max(want)
+    assert float(mag.min()) == 0.0

@@ -66,6 +66,13 @@ __device__ __forceinline__ v2f lds_rd(const v2f* q) { return *(lds_cvp)q; }
 #else
 __device__ __forceinline__ v2f lds_rd(const v2f* q) { return *q; }
 #endif
+typedef float v4f_ __attribute__((ext_vector_type(4)));
+// two table entries of a pair (TE layout) with one 16-byte read
+__device__ __forceinline__ void lds_rd_pair(const v2f* q, v2f& a, v2f& b) {
+    const v4f_ t = *reinterpret_cast<const v4f_*>(q);
+    a = t.xy;
+    b = t.zw;
+}
 
 template <bool INV>
 __device__ __forceinline__ v2f ctw(v2f a, v2f w) { return INV ? cmulc(a, w) : cmul(a, w); }
@@ -174,10 +181,23 @@ __device__ __forceinline__ void pair_inv(v2f Xk, v2f Xmk, v2f w, v2f& zk, v2f& z
     zk.x = A.x - Zo.y;  zk.y = A.y + Zo.x;
     zm.x = A.x + Zo.y;  zm.y = Zo.x - A.y;
 }
+#ifndef GL_PROJ_EPS
+#define GL_PROJ_EPS 1
+#endif
 __device__ __forceinline__ v2f project(v2f X, float m) {
+#if GL_PROJ_EPS
+    // select-free form: nudging the real part by 2^-60 turns an exactly zero bin into (2^-60, 0), whose
+    // projection is (mag, 0) = mag * exp(1j * angle(0)) (audio_utilities.py:181-183) without a compare;
+    // a bin that large enough to matter (|X| > 2^-36 ~ 1.5e-11) does not see the nudge in fp32
+    const v2f Xe = X + (v2f){0x1p-60f, 0.0f};
+    const float r2 = fmaxf(fmaf(Xe.x, Xe.x, Xe.y * Xe.y), 0x1p-124f);
+    const float sc = m * __builtin_amdgcn_rsqf(r2);
+    return Xe * (v2f){sc, sc};
+#else
     float2 r = gl_project(make_float2(X.x, X.y), m);
     v2f o = {r.x, r.y};
     return o;
+#endif
 }
 
 struct FastArgs {
@@ -447,16 +467,25 @@ __global__ void __launch_bounds__(64) k_fast2048(FastArgs p) {
 #ifndef GL_ABL
 #define GL_ABL 0   // timing experiments only: 1 skip LDS transposes, 2 skip projection step, 4 constant twiddles
 #endif
+#ifndef GL_SETPRIO
+#define GL_SETPRIO 0   // experiment: raise the wave's issue priority while it feeds the LDS queue
+#endif
+__device__ __forceinline__ void prio_hi() { if (GL_SETPRIO) __builtin_amdgcn_s_setprio(GL_SETPRIO); }
+__device__ __forceinline__ void prio_lo() { if (GL_SETPRIO) __builtin_amdgcn_s_setprio(0); }
 constexpr int kEx2StrideInv = 132;   // inverse exchange-2 stride: conflict-free b64 reads
 static_assert(kScratch >= 8 * kEx2StrideInv, "scratch too small");
 
 constexpr int kT2Win = 0;       // 16: (w[2(l+64j)], w[2(l+64j)+1])
 constexpr int kT2WinSc = 16;    // 16: the same / 1024
 constexpr int kT2Tw1 = 32;      // 15: W1024^(l*k2), k2 = 1..15
-constexpr int kT2Tw2 = 47;      // 7:  W64^(a*d), d = 1..7
-constexpr int kT2Twp = 54;      // 9:  -i * W2048^(kP[u])
-constexpr int kT2Entries = 63;   // entries copied to LDS
-constexpr int kT2Zero = 63;      // global-only: one row of zeros (the "no tail" operand of load_row)
+constexpr int kT2Tw2 = 48;      // 7:  W64^(a*d), d = 1..7   (every group starts on an even entry: pair reads)
+constexpr int kT2Twp = 56;      // 9:  -i * W2048^(kP[u])
+constexpr int kT2Entries = 66;   // entries copied to LDS (33 KB)
+constexpr int kT2Zero = 66;      // global-only: one row of zeros after the table (the "no tail" operand of load_row)
+// Entries are stored in pairs, [e/2][lane][e&1]: a lane's entries 2p and 2p+1 are 16 contiguous bytes, so
+// constants that are used together (two window values, two twiddles) arrive with one ds_read_b128
+// (full LDS rate) instead of two reads.  tabl = smem + 2*lane; entry e of the lane is tabl[TE(e)].
+#define TE(e) ((((e) >> 1) * 128) + ((e) & 1))
 
 // Phase timing for kernel studies (-DGL_STAMPS): every phase boundary drains the LDS queue and
 // reads the shader clock; lane 0 of every wave adds its per-phase totals to g_stamp at exit.
@@ -497,13 +526,23 @@ struct Stamps {
 };
 #endif
 
+#ifndef GL_TW2_REG
+#define GL_TW2_REG 0   // 1: the seven W64 twiddles live in registers (callers pass them) instead of LDS reads
+#endif
 __device__ __forceinline__ void fft_forward_1024(v2f* z, v2f* ex, int l, int a3, int g3, int kloB,
-                                                 const v2f* __restrict__ tabl, Stamps& st) {
+                                                 const v2f* __restrict__ tabl, Stamps& st, const v2f* w2r = nullptr) {
     dft16<false>(z);
 #pragma unroll
-    for (int k2 = 1; k2 < 16; ++k2) z[k2] = cmul(z[k2], (GL_ABL & 4) ? (v2f){0.6f, 0.8f} : lds_rd(&tabl[(kT2Tw1 + k2 - 1) * 64]));
+    for (int pp = 0; pp < 7; ++pp) {
+        v2f wa, wb;
+        lds_rd_pair(&tabl[TE(kT2Tw1 + 2 * pp)], wa, wb);
+        z[2 * pp + 1] = cmul(z[2 * pp + 1], wa);
+        z[2 * pp + 2] = cmul(z[2 * pp + 2], wb);
+    }
+    z[15] = cmul(z[15], lds_rd(&tabl[TE(kT2Tw1 + 14)]));
     st.mark(1);
     if (!(GL_ABL & 1)) {
+    prio_hi();
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int k2 = 0; k2 < 16; ++k2) ex[k2 * kEx1Stride + l] = z[k2];
@@ -512,18 +551,27 @@ __device__ __forceinline__ void fft_forward_1024(v2f* z, v2f* ex, int l, int a3,
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int bb = 0; bb < 8; ++bb) z[8 * h + bb] = lds_rd(&ex[(g3 + 8 * h) * kEx1Stride + a3 + 8 * bb]);
+    prio_lo();
     }
     st.mark(2);
     dft8<false>(z);
     dft8<false>(z + 8);
 #pragma unroll
-    for (int d = 1; d < 8; ++d) {
-        v2f w = (GL_ABL & 4) ? (v2f){0.6f, 0.8f} : lds_rd(&tabl[(kT2Tw2 + d - 1) * 64]);
-        z[d] = cmul(z[d], w);
-        z[8 + d] = cmul(z[8 + d], w);
+    for (int pp = 0; pp < 4; ++pp) {       // d = 2pp+1, 2pp+2
+        v2f wa, wb;
+        if (w2r) { wa = w2r[2 * pp]; wb = w2r[pp < 3 ? 2 * pp + 1 : 2 * pp]; }
+        else if (pp < 3) lds_rd_pair(&tabl[TE(kT2Tw2 + 2 * pp)], wa, wb);
+        else wa = wb = lds_rd(&tabl[TE(kT2Tw2 + 6)]);
+        z[2 * pp + 1] = cmul(z[2 * pp + 1], wa);
+        z[8 + 2 * pp + 1] = cmul(z[8 + 2 * pp + 1], wa);
+        if (pp < 3) {
+            z[2 * pp + 2] = cmul(z[2 * pp + 2], wb);
+            z[8 + 2 * pp + 2] = cmul(z[8 + 2 * pp + 2], wb);
+        }
     }
     st.mark(3);
     if (!(GL_ABL & 1)) {
+    prio_hi();
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -532,6 +580,7 @@ __device__ __forceinline__ void fft_forward_1024(v2f* z, v2f* ex, int l, int a3,
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int a = 0; a < 8; ++a) { z[a] = lds_rd(&ex[a * kEx2Stride + l]); z[8 + a] = lds_rd(&ex[a * kEx2Stride + kloB]); }
+    prio_lo();
     }
     st.mark(4);
     dft8<false>(z);
@@ -540,11 +589,12 @@ __device__ __forceinline__ void fft_forward_1024(v2f* z, v2f* ex, int l, int a3,
 }
 
 __device__ __forceinline__ void fft_inverse_1024(v2f* z, v2f* ex, int l, int a3, int g3, int kloB,
-                                                 const v2f* __restrict__ tabl, Stamps& st) {
+                                                 const v2f* __restrict__ tabl, Stamps& st, const v2f* w2r = nullptr) {
     dft8<true>(z);
     dft8<true>(z + 8);
     st.mark(7);
     if (!(GL_ABL & 1)) {
+    prio_hi();
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int a = 0; a < 8; ++a) { ex[a * kEx2StrideInv + l] = z[a]; ex[a * kEx2StrideInv + kloB] = z[8 + a]; }
@@ -553,18 +603,27 @@ __device__ __forceinline__ void fft_inverse_1024(v2f* z, v2f* ex, int l, int a3,
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int d = 0; d < 8; ++d) z[8 * h + d] = lds_rd(&ex[a3 * kEx2StrideInv + 16 * d + g3 + 8 * h]);
+    prio_lo();
     }
     st.mark(8);
 #pragma unroll
-    for (int d = 1; d < 8; ++d) {
-        v2f w = (GL_ABL & 4) ? (v2f){0.6f, 0.8f} : lds_rd(&tabl[(kT2Tw2 + d - 1) * 64]);
-        z[d] = cmulc(z[d], w);
-        z[8 + d] = cmulc(z[8 + d], w);
+    for (int pp = 0; pp < 4; ++pp) {       // d = 2pp+1, 2pp+2
+        v2f wa, wb;
+        if (w2r) { wa = w2r[2 * pp]; wb = w2r[pp < 3 ? 2 * pp + 1 : 2 * pp]; }
+        else if (pp < 3) lds_rd_pair(&tabl[TE(kT2Tw2 + 2 * pp)], wa, wb);
+        else wa = wb = lds_rd(&tabl[TE(kT2Tw2 + 6)]);
+        z[2 * pp + 1] = cmulc(z[2 * pp + 1], wa);
+        z[8 + 2 * pp + 1] = cmulc(z[8 + 2 * pp + 1], wa);
+        if (pp < 3) {
+            z[2 * pp + 2] = cmulc(z[2 * pp + 2], wb);
+            z[8 + 2 * pp + 2] = cmulc(z[8 + 2 * pp + 2], wb);
+        }
     }
     dft8<true>(z);
     dft8<true>(z + 8);
     st.mark(9);
     if (!(GL_ABL & 1)) {
+    prio_hi();
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -573,10 +632,17 @@ __device__ __forceinline__ void fft_inverse_1024(v2f* z, v2f* ex, int l, int a3,
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int k2 = 0; k2 < 16; ++k2) z[k2] = lds_rd(&ex[k2 * kEx1Stride + l]);
+    prio_lo();
     }
     st.mark(10);
 #pragma unroll
-    for (int k2 = 1; k2 < 16; ++k2) z[k2] = cmulc(z[k2], (GL_ABL & 4) ? (v2f){0.6f, 0.8f} : lds_rd(&tabl[(kT2Tw1 + k2 - 1) * 64]));
+    for (int pp = 0; pp < 7; ++pp) {
+        v2f wa, wb;
+        lds_rd_pair(&tabl[TE(kT2Tw1 + 2 * pp)], wa, wb);
+        z[2 * pp + 1] = cmulc(z[2 * pp + 1], wa);
+        z[2 * pp + 2] = cmulc(z[2 * pp + 2], wb);
+    }
+    z[15] = cmulc(z[15], lds_rd(&tabl[TE(kT2Tw1 + 14)]));
     dft16<true>(z);
     st.mark(11);
 }
@@ -595,19 +661,25 @@ __device__ __forceinline__ void middle_project(v2f* z, bool l0, const float* m_l
     for (int c = 4; c < 8; ++c) { P[c] = sel(l0, z[8 + c - 4], z[c]); Q[c] = sel(l0, z[8 + 11 - c], z[15 - c]); }
     P[8] = z[4];
     Q[8] = z[4];
-#pragma unroll
-    for (int u = 0; u < 9; ++u) {
-        // w = -i*W2048^k.  2X[k] = (P + conj Q) + w*(P - conj Q), 2conj(X[M-k]) = the same with -w;
-        // the projection is scale-free and commutes with conj; back: 2z[k] = (X+Y) + (X-Y)*conj(w),
-        // 2z[M-k] = conj((X+Y) - (X-Y)*conj(w)).  The factor 2 is folded into the scaled window.
-        const v2f w = lds_rd(&tabl[(kT2Twp + u) * 64]);
+    // w = -i*W2048^k.  2X[k] = (P + conj Q) + w*(P - conj Q), 2conj(X[M-k]) = the same with -w;
+    // the projection is scale-free and commutes with conj; back: 2z[k] = (X+Y) + (X-Y)*conj(w),
+    // 2z[M-k] = conj((X+Y) - (X-Y)*conj(w)).  The factor 2 is folded into the scaled window.
+    auto unit = [&](int u, v2f w) {
         const v2f uu = pk_addc(P[u], Q[u]), vv = pk_subc(P[u], Q[u]);
         const v2f X = project(cmul_add(vv, w, uu), m_lo[u]);
         const v2f Y = project(cmul_sub(vv, w, uu), m_hi[u]);
         const v2f a2 = X + Y, b2 = X - Y;
         P[u] = cmulc_add(b2, w, a2);
         Q[u] = cmulc_subconj(b2, w, a2);
+    };
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+        v2f wa, wb;
+        lds_rd_pair(&tabl[TE(kT2Twp + 2 * pp)], wa, wb);
+        unit(2 * pp, wa);
+        unit(2 * pp + 1, wb);
     }
+    unit(8, lds_rd(&tabl[TE(kT2Twp + 8)]));
     z[0] = P[0];
 #pragma unroll
     for (int c = 1; c < 4; ++c) z[c] = P[c];
@@ -690,7 +762,7 @@ __global__ void __launch_bounds__(64 * kRRWaves, GL_RR_OCC) k_gl2048_regring(Ali
     const int b = grun / p.nruns;
     const int run = grun - b * p.nruns;
     v2f* ex = smem + kT2Entries * 64 + wave * kScratch;
-    const v2f* tabl = smem + l;
+    const v2f* tabl = smem + 2 * l;
     const int T = p.T;
     const int f0 = run * p.G;
     const int f1 = min(f0 + p.G, T);
@@ -754,6 +826,14 @@ __global__ void __launch_bounds__(64 * kRRWaves, GL_RR_OCC) k_gl2048_regring(Ali
     };
     float m_lo[9], m_hi[9];
     load_mags(f0, m_lo, m_hi);
+#if GL_TW2_REG
+    v2f w2reg[7];
+#pragma unroll
+    for (int d = 1; d < 8; ++d) w2reg[d - 1] = lds_rd(&tabl[TE(kT2Tw2 + d - 1)]);
+    const v2f* w2r = w2reg;
+#else
+    const v2f* w2r = nullptr;
+#endif
 
     // Drain the ring-fill loads here.  Otherwise the loop header inherits "xraw[8..15] still in
     // flight" from this prologue and the compiler guards every frame's window multiply with
@@ -790,9 +870,9 @@ __global__ void __launch_bounds__(64 * kRRWaves, GL_RR_OCC) k_gl2048_regring(Ali
 
         v2f z[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) z[j] = xraw[j] * lds_rd(&tabl[(kT2Win + j) * 64]);
+        for (int j = 0; j < 16; ++j) z[j] = xraw[j] * lds_rd(&tabl[TE(kT2Win + j)]);
         st.mark(0);
-        fft_forward_1024(z, ex, l, a3, g3, kloB, tabl, st);
+        fft_forward_1024(z, ex, l, a3, g3, kloB, tabl, st, w2r);
         if (!(GL_ABL & 2)) middle_project(z, l0, m_lo, m_hi, tabl);
         // the magnitude registers are free again: request the next frame's now, so the loads have
         // the inverse and the next forward transform to land (an HBM round trip under load is
@@ -801,10 +881,10 @@ __global__ void __launch_bounds__(64 * kRRWaves, GL_RR_OCC) k_gl2048_regring(Ali
         load_mags(more ? n + 1 : n, m_lo, m_hi);
 #endif
         st.mark(6);
-        fft_inverse_1024(z, ex, l, a3, g3, kloB, tabl, st);
+        fft_inverse_1024(z, ex, l, a3, g3, kloB, tabl, st, w2r);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            v2f w = lds_rd(&tabl[(kT2WinSc + j) * 64]);
+            v2f w = lds_rd(&tabl[TE(kT2WinSc + j)]);
             accr[j].x = fmaf(z[j].x, w.x, accr[j].x);
             accr[j].y = fmaf(z[j].y, w.y, accr[j].y);
         }
@@ -920,7 +1000,7 @@ __global__ void __launch_bounds__(64 * kP1Waves, 1) k_gl1024_pair(Pair1024Args p
     v2f* ex = smem + kT2Entries * 64 + wave * kP1WaveLds;
     float* xring = reinterpret_cast<float*>(ex + kScratch);
     float* acc = xring + kP1Ring;
-    const v2f* tabl = smem + l;
+    const v2f* tabl = smem + 2 * l;
 
     const int H = p.H, T = p.T;
     const int f0 = run * p.G;
@@ -974,7 +1054,7 @@ __global__ void __launch_bounds__(64 * kP1Waves, 1) k_gl1024_pair(Pair1024Args p
                 float xb = two ? xring[(base_b + l + 64 * j) & (kP1Ring - 1)] : 0.0f;
                 a_nz |= (xa != 0.0f);
                 b_nz |= (xb != 0.0f);
-                v2f w = tabl[(kT2Win + j) * 64];
+                v2f w = tabl[TE(kT2Win + j)];
                 z[j].x = xa * w.x;
                 z[j].y = xb * w.y;
             }
@@ -996,14 +1076,14 @@ __global__ void __launch_bounds__(64 * kP1Waves, 1) k_gl1024_pair(Pair1024Args p
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                v2f w = tabl[(kT2WinSc + j) * 64];
+                v2f w = tabl[TE(kT2WinSc + j)];
                 acc[(base_a + l + 64 * j) & (kP1Ring - 1)] += z[j].x * w.x;
             }
             __builtin_amdgcn_wave_barrier();
             if (two) {
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
-                    v2f w = tabl[(kT2WinSc + j) * 64];
+                    v2f w = tabl[TE(kT2WinSc + j)];
                     acc[(base_b + l + 64 * j) & (kP1Ring - 1)] += z[j].y * w.y;
                 }
             }
@@ -1168,9 +1248,10 @@ int ensure_table2(gl_plan* p) {
     const int N = p->n_fft;
     std::vector<float> tab((size_t)(kT2Entries + 1) * 64 * 2, 0.0f);
     const double pi = 3.14159265358979323846;
-    auto put = [&](int e, int l, double re, double im) {
-        tab[((size_t)e * 64 + l) * 2] = (float)re;
-        tab[((size_t)e * 64 + l) * 2 + 1] = (float)im;
+    auto put = [&](int e, int l, double re, double im) {      // pair layout, see TE()
+        const size_t at = ((size_t)(e >> 1) * 128 + 2 * (size_t)l + (e & 1)) * 2;
+        tab[at] = (float)re;
+        tab[at + 1] = (float)im;
     };
     auto Wre = [&](int n, long long k) { return cos(-2.0 * pi * (double)(k % n) / (double)n); };
     auto Wim = [&](int n, long long k) { return sin(-2.0 * pi * (double)(k % n) / (double)n); };

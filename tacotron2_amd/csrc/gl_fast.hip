@@ -472,8 +472,19 @@ __global__ void __launch_bounds__(64) k_fast2048(FastArgs p) {
 #endif
 __device__ __forceinline__ void prio_hi() { if (GL_SETPRIO) __builtin_amdgcn_s_setprio(GL_SETPRIO); }
 __device__ __forceinline__ void prio_lo() { if (GL_SETPRIO) __builtin_amdgcn_s_setprio(0); }
-constexpr int kEx2StrideInv = 132;   // inverse exchange-2 stride: conflict-free b64 reads
-static_assert(kScratch >= 8 * kEx2StrideInv, "scratch too small");
+// Transpose layouts of fft_forward_1024 / fft_inverse_1024.  Each exchange is written (or read) by a
+// lane as runs of 8 contiguous complex values, so that side moves 16 bytes per instruction
+// (4 x b128 instead of 8 x b64); the other side is 8-byte accesses at the permuted positions
+// pi(l) = (l&7)*10 + (l>>3) (exchange 1, rows of 80) and rho(i) = (i&15)*10 + (i>>4) (exchange 2, rows
+// of 166).  The pads (10 instead of 8, 166 instead of 160) make every access pattern at most 2-way
+// bank-conflicting (checked per instruction kind and lane group in oracle/sim_fast2048.py).
+constexpr int kE1P = 10, kE1S = 80;
+constexpr int kE2Q = 10, kE2S = 166;
+constexpr int kRScratch = 8 * kE2S;   // complex elements per wave (>= 16 * kE1S)
+static_assert(kRScratch >= 16 * kE1S, "scratch too small");
+__device__ __forceinline__ void lds_wr_pair(v2f* q, v2f a, v2f b) {
+    *reinterpret_cast<v4f_*>(q) = (v4f_){a.x, a.y, b.x, b.y};
+}
 
 constexpr int kT2Win = 0;       // 16: (w[2(l+64j)], w[2(l+64j)+1])
 constexpr int kT2WinSc = 16;    // 16: the same / 1024
@@ -531,6 +542,9 @@ struct Stamps {
 #endif
 __device__ __forceinline__ void fft_forward_1024(v2f* z, v2f* ex, int l, int a3, int g3, int kloB,
                                                  const v2f* __restrict__ tabl, Stamps& st, const v2f* w2r = nullptr) {
+    const int piL = a3 * kE1P + g3;                                    // pi(l)
+    const int rhoL = (l & 15) * kE2Q + (l >> 4);                       // rho(l)
+    const int rhoK = (kloB & 15) * kE2Q + (kloB >> 4);                 // rho(128 - l) (lane 0: rho(64))
     dft16<false>(z);
 #pragma unroll
     for (int pp = 0; pp < 7; ++pp) {
@@ -545,12 +559,13 @@ __device__ __forceinline__ void fft_forward_1024(v2f* z, v2f* ex, int l, int a3,
     prio_hi();
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int k2 = 0; k2 < 16; ++k2) ex[k2 * kEx1Stride + l] = z[k2];
+    for (int k2 = 0; k2 < 16; ++k2) ex[k2 * kE1S + piL] = z[k2];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int bb = 0; bb < 8; ++bb) z[8 * h + bb] = lds_rd(&ex[(g3 + 8 * h) * kEx1Stride + a3 + 8 * bb]);
+        for (int bb = 0; bb < 8; bb += 2)
+            lds_rd_pair(&ex[(g3 + 8 * h) * kE1S + a3 * kE1P + bb], z[8 * h + bb], z[8 * h + bb + 1]);
     prio_lo();
     }
     st.mark(2);
@@ -576,10 +591,11 @@ __device__ __forceinline__ void fft_forward_1024(v2f* z, v2f* ex, int l, int a3,
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int d = 0; d < 8; ++d) ex[a3 * kEx2Stride + 16 * d + g3 + 8 * h] = z[8 * h + d];
+        for (int d = 0; d < 8; d += 2)
+            lds_wr_pair(&ex[a3 * kE2S + (g3 + 8 * h) * kE2Q + d], z[8 * h + d], z[8 * h + d + 1]);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int a = 0; a < 8; ++a) { z[a] = lds_rd(&ex[a * kEx2Stride + l]); z[8 + a] = lds_rd(&ex[a * kEx2Stride + kloB]); }
+    for (int a = 0; a < 8; ++a) { z[a] = lds_rd(&ex[a * kE2S + rhoL]); z[8 + a] = lds_rd(&ex[a * kE2S + rhoK]); }
     prio_lo();
     }
     st.mark(4);
@@ -590,6 +606,9 @@ __device__ __forceinline__ void fft_forward_1024(v2f* z, v2f* ex, int l, int a3,
 
 __device__ __forceinline__ void fft_inverse_1024(v2f* z, v2f* ex, int l, int a3, int g3, int kloB,
                                                  const v2f* __restrict__ tabl, Stamps& st, const v2f* w2r = nullptr) {
+    const int piL = a3 * kE1P + g3;                                    // pi(l)
+    const int rhoL = (l & 15) * kE2Q + (l >> 4);                       // rho(l)
+    const int rhoK = (kloB & 15) * kE2Q + (kloB >> 4);                 // rho(128 - l) (lane 0: rho(64))
     dft8<true>(z);
     dft8<true>(z + 8);
     st.mark(7);
@@ -597,12 +616,13 @@ __device__ __forceinline__ void fft_inverse_1024(v2f* z, v2f* ex, int l, int a3,
     prio_hi();
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int a = 0; a < 8; ++a) { ex[a * kEx2StrideInv + l] = z[a]; ex[a * kEx2StrideInv + kloB] = z[8 + a]; }
+    for (int a = 0; a < 8; ++a) { ex[a * kE2S + rhoL] = z[a]; ex[a * kE2S + rhoK] = z[8 + a]; }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int d = 0; d < 8; ++d) z[8 * h + d] = lds_rd(&ex[a3 * kEx2StrideInv + 16 * d + g3 + 8 * h]);
+        for (int d = 0; d < 8; d += 2)
+            lds_rd_pair(&ex[a3 * kE2S + (g3 + 8 * h) * kE2Q + d], z[8 * h + d], z[8 * h + d + 1]);
     prio_lo();
     }
     st.mark(8);
@@ -628,10 +648,11 @@ __device__ __forceinline__ void fft_inverse_1024(v2f* z, v2f* ex, int l, int a3,
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int bb = 0; bb < 8; ++bb) ex[(g3 + 8 * h) * kEx1Stride + a3 + 8 * bb] = z[8 * h + bb];
+        for (int bb = 0; bb < 8; bb += 2)
+            lds_wr_pair(&ex[(g3 + 8 * h) * kE1S + a3 * kE1P + bb], z[8 * h + bb], z[8 * h + bb + 1]);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int k2 = 0; k2 < 16; ++k2) z[k2] = lds_rd(&ex[k2 * kEx1Stride + l]);
+    for (int k2 = 0; k2 < 16; ++k2) z[k2] = lds_rd(&ex[k2 * kE1S + piL]);
     prio_lo();
     }
     st.mark(10);
@@ -748,7 +769,7 @@ constexpr int kRRWaves = GL_RR_WAVES;        // waves per workgroup; they only s
 template <int HS>
 __global__ void __launch_bounds__(64 * kRRWaves, GL_RR_OCC) k_gl2048_regring(AlignedArgs p) {
     // one LDS array (table + per-wave transpose scratch): 32 KB + 12 x 9 KB = 140 KB -> 1 WG / CU
-    __shared__ __attribute__((aligned(16))) v2f smem[kT2Entries * 64 + kRRWaves * kScratch];
+    __shared__ __attribute__((aligned(16))) v2f smem[kT2Entries * 64 + kRRWaves * kRScratch];
     constexpr int H = 128 * HS;
     constexpr int OVR = 16 - HS;                 // rows shared with the next frame / next run
     constexpr int ovl = kN - H;
@@ -761,7 +782,7 @@ __global__ void __launch_bounds__(64 * kRRWaves, GL_RR_OCC) k_gl2048_regring(Ali
     if (grun >= p.B * p.nruns) return;           // wave-uniform; no barrier after this point
     const int b = grun / p.nruns;
     const int run = grun - b * p.nruns;
-    v2f* ex = smem + kT2Entries * 64 + wave * kScratch;
+    v2f* ex = smem + kT2Entries * 64 + wave * kRScratch;
     const v2f* tabl = smem + 2 * l;
     const int T = p.T;
     const int f0 = run * p.G;
@@ -936,7 +957,7 @@ __global__ void __launch_bounds__(64 * kRRWaves, GL_RR_OCC) k_gl2048_regring(Ali
 constexpr int kN1 = 1024;
 constexpr int kP1Waves = 4;
 constexpr int kP1Ring = 2048;      // floats; >= N + H for every hop <= N
-constexpr int kP1WaveLds = kScratch + kP1Ring;   // v2f units per wave: transpose scratch + two float rings
+constexpr int kP1WaveLds = kRScratch + kP1Ring;   // v2f units per wave: transpose scratch + two float rings
 
 struct Pair1024Args {
     const float* x_in;      // [B][L]
@@ -998,7 +1019,7 @@ __global__ void __launch_bounds__(64 * kP1Waves, 1) k_gl1024_pair(Pair1024Args p
     __syncthreads();
     if (run >= p.nruns) return;                  // wave-uniform; no barrier after this point
     v2f* ex = smem + kT2Entries * 64 + wave * kP1WaveLds;
-    float* xring = reinterpret_cast<float*>(ex + kScratch);
+    float* xring = reinterpret_cast<float*>(ex + kRScratch);
     float* acc = xring + kP1Ring;
     const v2f* tabl = smem + 2 * l;
 

@@ -236,6 +236,96 @@ def check_two_frames():
     print("two-frames-per-FFT split (n_fft 1024) ok")
 
 
+# --------------------------------------------------------------------------------------------
+# LDS layouts of the four transposes (gl_fast.hip: kE1P/kE1S, kE2Q/kE2S).  One side of every
+# exchange moves runs of 8 contiguous complex values (16-byte instructions), the other side 8-byte
+# accesses at permuted positions.  Checked here: (1) the permuted layout routes every value to the
+# lane/register the plain transposes (n = a + 8b + 64 n2 maps above) send it to; (2) the worst bank
+# conflict of every access pattern, per instruction kind and hardware lane group
+# (MI355X_MICROARCH.md, LDS table), is at most 2-way.
+# --------------------------------------------------------------------------------------------
+E1P, E1S, E2Q, E2S = 10, 80, 10, 166
+
+
+def _pi(l):
+    return (l & 7) * E1P + (l >> 3)
+
+
+def _rho(i):
+    return (i & 15) * E2Q + (i >> 4)
+
+
+def _klo(l):
+    return 128 - l if l else 64
+
+
+def check_exchange_routing():
+    lanes = np.arange(64)
+    a3, g3 = lanes & 7, lanes >> 3
+    # exchange 1 forward: lane l writes z[k2] to (row k2, pi(l)); lane (a3,g3) reads rows g3+8h, a3*P+bb
+    lds = np.full(8 * E2S, -1, dtype=np.int64)
+    for k2 in range(16):
+        lds[k2 * E1S + _pi(lanes)] = k2 * 64 + lanes            # tag = (k2, writer lane)
+    for h in range(2):
+        for bb in range(8):
+            got = lds[(g3 + 8 * h) * E1S + a3 * E1P + bb]
+            want = (g3 + 8 * h) * 64 + (a3 + 8 * bb)            # plain: ex[(g3+8h)*S + a3 + 8bb]
+            assert np.array_equal(got, want)
+    # exchange 2 forward: lane (a3,g3) writes z[8h+d] to (row a3, (g3+8h)*Q+d); lane l reads rho(l), rho(klo)
+    lds[:] = -1
+    for h in range(2):
+        for d in range(8):
+            lds[a3 * E2S + (g3 + 8 * h) * E2Q + d] = a3 * 128 + (16 * d + g3 + 8 * h)   # tag = (row, plain index)
+    klo = np.array([_klo(l) for l in lanes])
+    for a in range(8):
+        assert np.array_equal(lds[a * E2S + _rho(lanes)], a * 128 + lanes)
+        assert np.array_equal(lds[a * E2S + _rho(klo)], a * 128 + klo)
+    assert 16 * E1S <= 8 * E2S and max(_rho(i) for i in range(128)) < E2S and max(_pi(l) for l in range(64)) < E1S
+    return True
+
+
+_R128 = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)),
+         list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32))]
+_R128 = _R128 + [[32 + x for x in g] for g in _R128]
+_R64 = [list(range(32)), list(range(32, 64))]
+_W64 = [list(range(16 * i, 16 * i + 16)) for i in range(4)]
+_W128 = [list(range(8 * i, 8 * i + 8)) for i in range(8)]
+
+
+def _worst_conflict(groups, addr_dw, ndw, nbanks):
+    worst = 0
+    for g in groups:
+        per_bank = {}
+        for l in g:
+            for k in range(ndw):
+                per_bank.setdefault((addr_dw(l) + k) % nbanks, set()).add(addr_dw(l) + k)
+        worst = max(worst, max(len(v) for v in per_bank.values()))
+    return worst
+
+
+def exchange_bank_conflicts():
+    """-> {pattern: worst n-way conflict} (1 = conflict-free)."""
+    a3 = lambda l: l & 7
+    g3 = lambda l: l >> 3
+    out = {}
+    run1 = lambda h, c: (lambda l: 2 * ((g3(l) + 8 * h) * E1S + a3(l) * E1P + 2 * c))
+    run2 = lambda h, c: (lambda l: 2 * (a3(l) * E2S + (g3(l) + 8 * h) * E2Q + 2 * c))
+    hc = [(h, c) for h in range(2) for c in range(4)]
+    out["ex1 fwd write b64"] = _worst_conflict(_W64, lambda l: 2 * _pi(l), 2, 32)
+    out["ex1 fwd read b128"] = max(_worst_conflict(_R128, run1(h, c), 4, 64) for h, c in hc)
+    out["ex1 inv write b128"] = max(_worst_conflict(_W128, run1(h, c), 4, 32) for h, c in hc)
+    out["ex1 inv read b64"] = _worst_conflict(_R64, lambda l: 2 * _pi(l), 2, 64)
+    out["ex2 fwd write b128"] = max(_worst_conflict(_W128, run2(h, c), 4, 32) for h, c in hc)
+    out["ex2 fwd read b64"] = max(_worst_conflict(_R64, lambda l: 2 * _rho(l), 2, 64),
+                                  _worst_conflict(_R64, lambda l: 2 * _rho(_klo(l)), 2, 64))
+    out["ex2 inv write b64"] = max(_worst_conflict(_W64, lambda l: 2 * _rho(l), 2, 32),
+                                   _worst_conflict(_W64, lambda l: 2 * _rho(_klo(l)), 2, 32))
+    out["ex2 inv read b128"] = max(_worst_conflict(_R128, run2(h, c), 4, 64) for h, c in hc)
+    return out
+
+
 if __name__ == "__main__":
+    check_exchange_routing()
+    print(exchange_bank_conflicts())
     main()
     check_two_frames()

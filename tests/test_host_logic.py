@@ -72,3 +72,21 @@ def test_fails_loudly_without_gpu():
         au.stft_for_reconstruction(np.zeros(200), 64, 16)
     with pytest.raises(RuntimeError):
         griffin_lim.save_mel_to_wav(np.ones((80, 5), dtype=np.float32))
+
+
+def test_fused_kernel_lds_exchange_layouts():
+    """The permuted LDS layouts of the fused kernels' four transposes (gl_fast.hip kE1P/kE1S/kE2Q/kE2S)
+    route every value where the plain transposes do, and no access pattern is worse than 2-way
+    bank-conflicting (lane-level model in oracle/sim_fast2048.py; no GPU needed)."""
+    import os
+    import re
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "oracle"))
+    import sim_fast2048 as sim
+    src = open(os.path.join(root, "tacotron2_amd", "csrc", "gl_fast.hip")).read()
+    m = re.search(r"kE1P = (\d+), kE1S = (\d+);\s*constexpr int kE2Q = (\d+), kE2S = (\d+);", src)
+    assert m and tuple(map(int, m.groups())) == (sim.E1P, sim.E1S, sim.E2Q, sim.E2S)   # model == kernel constants
+    assert sim.check_exchange_routing()
+    worst = sim.exchange_bank_conflicts()
+    assert max(worst.values()) <= 2, worst

@@ -88,6 +88,21 @@ int gl_mel_to_mag(gl_plan* plan, const float* filterbank, const float* mel, floa
 int gl_logmel_to_mag(gl_plan* plan, const float* filterbank, const float* logmel, float* mag,
                      int n_mels, float compression_factor, int B, int T, void* stream);
 
+/* N3  the forward analysis path, data.py:100-116 (audiopath_to_mel after the file is loaded):
+ *   stft = librosa.stft(y, n_fft)  -- hop = the plan's hop (librosa's default is n_fft/4), periodic Hann,
+ *   center=True: frame t covers y[t*H - N/2, t*H + N/2), T = 1 + len / H frames (gl_analysis_num_frames);
+ *   pad_mode 1 = edges reflected (librosa < 0.10, the reference's era), 0 = zero-filled (librosa >= 0.10);
+ *   mag = |stft| (data.py:111), mel = filterbank @ mag on MFMA (data.py:112),
+ *   logmel = log(max(mel, clip_min) * compression_factor) (data.py:80-81, clip_min 0.01, factor 1).
+ *   y : [B][y_stride] fp32 (first `len` samples);  mag : [B][T][F] fp32 out (also the scratch of the
+ *   contraction);  logmel : [B][n_mels][T] fp32 out -- the (80, T) layout the reference's mels have.
+ *   librosa is not available to pin this against: parity unpinned, checked against a numpy
+ *   statement of librosa's documented algorithm.                                                       */
+int gl_analysis_num_frames(int hop, long long len);
+int gl_wav_to_logmel(gl_plan* plan, const float* y, long long y_stride, long long len, const float* filterbank,
+                     float* mag, float* logmel, int n_mels, int pad_mode, float clip_min, float compression_factor,
+                     int B, void* stream);
+
 /* a-3 + a-6  reconstruct_signal_griffin_lim(mag, fft_size, hopsamp, iterations)
  *                                                     audio_utilities.py:154-188
  *   mag   : [B][T][F] fp32   (rows = time slices)

@@ -166,6 +166,29 @@ def griffin_lim_variant(mag, fft_size, hopsamp, iterations, x0, normalize=False,
     return t
 
 
+# --------------------------------------------------------------------------
+# N3  forward analysis, data.py:100-116.  PARITY UNPINNED: librosa is absent (see the header);
+# this is librosa.stft's documented algorithm (center=True, window='hann' periodic,
+# hop_length = n_fft // 4 by default, pad_mode 'reflect' before 0.10 / 'constant' from 0.10).
+# --------------------------------------------------------------------------
+def stft_librosa_doc(y, n_fft, hop=None, pad_mode="reflect"):
+    n_fft = int(n_fft)
+    hop = n_fft // 4 if hop is None else int(hop)
+    y = np.asarray(y, dtype=np.float64)
+    yp = np.pad(y, n_fft // 2, mode=pad_mode)
+    w = 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n_fft) / n_fft)
+    n_frames = 1 + len(y) // hop
+    idx = (np.arange(n_frames) * hop)[:, None] + np.arange(n_fft)[None, :]
+    return np.fft.rfft(w[None, :] * yp[idx], axis=1)          # (T, F), rows = frames
+
+
+def audio_to_logmel(y, filterbank, n_fft, hop=None, pad_mode="reflect", compression_factor=1.0):
+    """data.py:110-114: log(clip(filterbank @ |stft|, 0.01) * compression_factor) -> (n_mels, T)."""
+    mag = np.abs(stft_librosa_doc(y, n_fft, hop, pad_mode))
+    mel = np.dot(np.asarray(filterbank, dtype=np.float64), mag.T)
+    return np.log(np.clip(mel, a_min=0.01, a_max=None) * compression_factor), mag
+
+
 def spectral_convergence(x, mag, fft_size, hopsamp, fit_gain=True):
     """|| |STFT(x)|/c - mag ||_F / || mag ||_F  (SURVEY 8d parity gate).  The
     reference ISTFT applies no window-sum normalisation, so x carries a gain of

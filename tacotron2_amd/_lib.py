@@ -33,6 +33,10 @@ SIGNATURES = {
                                      ctypes.c_int, ctypes.c_void_p]),
     "gl_logmel_to_mag": (ctypes.c_int, [_plan_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_float,
                                         ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "gl_analysis_num_frames": (ctypes.c_int, [ctypes.c_int, ctypes.c_longlong]),
+    "gl_wav_to_logmel": (ctypes.c_int, [_plan_p, _c_float_p, ctypes.c_longlong, ctypes.c_longlong, _c_float_p,
+                                        _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                                        ctypes.c_float, ctypes.c_int, ctypes.c_void_p]),
     "gl_run": (ctypes.c_int, [_plan_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                               ctypes.c_void_p]),
     "gl_plan_prepare": (ctypes.c_int, [_plan_p]),

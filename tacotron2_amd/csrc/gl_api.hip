@@ -152,7 +152,7 @@ int gl_plan_destroy(gl_plan* p) {
     DeviceGuard guard(p->device);
     void* ptrs[] = {p->d_window, p->d_tw,     p->d_frames, p->d_xa,      p->d_xb,
                     p->d_tail_a, p->d_tail_b, p->d_fast_tab, p->d_peaks, p->d_fast_tab2, p->d_magp,
-                    p->d_inv_wsum, p->d_prev};
+                    p->d_inv_wsum, p->d_prev, p->d_window_p};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     delete p;
@@ -237,6 +237,32 @@ int gl_logmel_to_mag(gl_plan* p, const float* filterbank, const float* logmel, f
     DeviceGuard guard(p->device);
     return gl_mel_launch(filterbank, logmel, mag, n_mels, p->n_fft / 2 + 1, B, T, true, compression_factor,
                          (p->opt_flags & GL_OPT_CLAMP_MAG) != 0, (hipStream_t)stream);
+}
+
+int gl_analysis_num_frames(int hop, long long len) {
+    if (hop < 1 || len < 1) return 0;
+    return (int)(1 + len / hop);      // librosa.stft(center=True): 1 + len // hop_length
+}
+
+int gl_wav_to_logmel(gl_plan* p, const float* y, long long y_stride, long long len, const float* filterbank,
+                     float* mag, float* logmel, int n_mels, int pad_mode, float clip_min, float compression_factor,
+                     int B, void* stream) {
+    if (!p || !y || !filterbank || !mag || !logmel) return gl_set_error(GL_ERR_INVALID, "gl_wav_to_logmel: NULL argument");
+    const int T = gl_analysis_num_frames(p->hop, len);
+    int rc = check_call(p, B, T > 0 ? T : 1, "gl_wav_to_logmel");
+    if (rc) return rc;
+    if (len < 1 || y_stride < len) return gl_set_error(GL_ERR_INVALID, "gl_wav_to_logmel: bad len/stride");
+    if (pad_mode != 0 && pad_mode != 1) return gl_set_error(GL_ERR_INVALID, "gl_wav_to_logmel: pad_mode must be 0 or 1");
+    if (pad_mode == 1 && len <= p->n_fft / 2)
+        return gl_set_error(GL_ERR_INVALID, "gl_wav_to_logmel: reflect padding needs len > n_fft/2 (got %lld)", len);
+    if (n_mels < 1 || n_mels > 128) return gl_set_error(GL_ERR_INVALID, "gl_wav_to_logmel: n_mels=%d outside [1, 128]", n_mels);
+    if (!(compression_factor > 0.0f)) return gl_set_error(GL_ERR_INVALID, "gl_wav_to_logmel: compression_factor must be > 0");
+    DeviceGuard guard(p->device);
+    hipStream_t st = (hipStream_t)stream;
+    rc = gl_analysis_mag(p, y, y_stride, len, mag, pad_mode, B, T, st);
+    if (rc) return rc;
+    return gl_mag_to_logmel_launch(filterbank, mag, logmel, n_mels, p->n_fft / 2 + 1, B, T, clip_min,
+                                   compression_factor, st);
 }
 
 int gl_run(gl_plan* p, const float* mag, const float* x0, float* x_out, int iters, int B, int T, void* stream) {

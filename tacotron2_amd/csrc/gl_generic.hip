@@ -7,6 +7,10 @@
 //
 // Replaces: audio_utilities.py:91-92 (frame*window, rfft), :181-183 (projection),
 //           :112-113 (irfft, window, overlap-add).
+#include <math.h>
+
+#include <vector>
+
 #include "gl_internal.h"
 
 namespace {
@@ -84,6 +88,52 @@ __global__ void __launch_bounds__(kThreads) k_generic_stft(const float* __restri
             rfft_pair(Z[k], Z[M - k], tw[k], Xk, Xmk);
             out[k] = Xk;
             out[M - k] = Xmk;
+        }
+    }
+}
+
+// N3  data.py:110-111  np.absolute(librosa.stft(y, n_fft)): centred frames (frame t covers
+// y[t*H - N/2 : t*H + N/2]), edges reflected (numpy 'reflect': y[-i] = y[i], y[len-1+i] = y[len-1-i])
+// or zero-filled, periodic Hann, magnitude only.  out: [B][T][M+1].
+__global__ void __launch_bounds__(kThreads) k_analysis_mag(const float* __restrict__ y, long long y_stride,
+                                                           long long len, float* __restrict__ out,
+                                                           const float* __restrict__ win,
+                                                           const float2* __restrict__ tw, int N, int H, int T,
+                                                           int reflect) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* a = reinterpret_cast<float2*>(smem_raw);
+    const int M = N >> 1;
+    float2* b = a + M;
+    const int t = blockIdx.x, bi = blockIdx.y;
+    const float* yr = y + (long long)bi * y_stride;
+    const long long s0 = (long long)t * H - M;
+    for (int n = threadIdx.x; n < M; n += blockDim.x) {
+        float v[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            long long s = s0 + 2 * n + e;
+            bool inside = (s >= 0 && s < len);
+            if (!inside && reflect) {
+                s = s < 0 ? -s : 2 * (len - 1) - s;
+                inside = (s >= 0 && s < len);
+            }
+            v[e] = inside ? yr[s] : 0.0f;
+        }
+        a[n] = make_float2(win[2 * n] * v[0], win[2 * n + 1] * v[1]);
+    }
+    __syncthreads();
+    float2* Z = wg_fft<false>(a, b, M, N, tw);
+    float* orow = out + ((long long)bi * T + t) * (M + 1);
+    for (int k = threadIdx.x; k <= M / 2; k += blockDim.x) {
+        if (k == 0) {
+            float2 z = Z[0];
+            orow[0] = fabsf(z.x + z.y);
+            orow[M] = fabsf(z.x - z.y);
+        } else {
+            float2 Xk, Xmk;
+            rfft_pair(Z[k], Z[M - k], tw[k], Xk, Xmk);
+            orow[k] = sqrtf(fmaf(Xk.x, Xk.x, Xk.y * Xk.y));
+            orow[M - k] = sqrtf(fmaf(Xmk.x, Xmk.x, Xmk.y * Xmk.y));
         }
     }
 }
@@ -197,6 +247,23 @@ int ensure_pingpong(gl_plan* p) {
 }
 
 }  // namespace
+
+int gl_analysis_mag(gl_plan* p, const float* y, long long y_stride, long long len, float* mag, int reflect, int B,
+                    int T, hipStream_t st) {
+    const int N = p->n_fft;
+    if (!p->d_window_p) {      // scipy.signal.get_window('hann', N, fftbins=True): 0.5 - 0.5 cos(2 pi n / N)
+        std::vector<float> w(N);
+        for (int n = 0; n < N; ++n) w[n] = (float)(0.5 - 0.5 * cos(2.0 * 3.14159265358979323846 * n / (double)N));
+        int rc = gl_plan_alloc(p, (void**)&p->d_window_p, sizeof(float) * N);
+        if (rc) return rc;
+        GL_HIP_CHECK(hipMemcpy(p->d_window_p, w.data(), sizeof(float) * N, hipMemcpyHostToDevice));
+    }
+    size_t lds = (size_t)N * sizeof(float2);
+    hipLaunchKernelGGL(k_analysis_mag, dim3(T, B), dim3(kThreads), lds, st, y, y_stride, len, mag, p->d_window_p,
+                       p->d_tw, N, p->hop, T, reflect);
+    GL_HIP_CHECK(hipGetLastError());
+    return 0;
+}
 
 int gl_generic_prepare(gl_plan* p) {
     int rc = ensure_frames(p);

@@ -31,6 +31,7 @@ struct gl_plan {
     float* d_inv_wsum;  // [L(wsum_T)] 1 / sum_t w^2(s - tH)  (lazy, rebuilt when T changes)
     int wsum_T;
     float* d_prev;      // [max_B][L] previous iterate for the momentum option (lazy)
+    float* d_window_p;  // [N] periodic Hann of the analysis path (lazy)
     long long bytes;
 };
 
@@ -54,6 +55,8 @@ int gl_generic_run(gl_plan* p, const float* mag, const float* x0, float* x_out, 
                    hipStream_t st);
 
 int gl_generic_prepare(gl_plan* p);
+int gl_analysis_mag(gl_plan* p, const float* y, long long y_stride, long long len, float* mag, int reflect, int B,
+                    int T, hipStream_t st);
 
 // ---- fused wave-per-frame kernels: gl_fast.hip -----------------------------------
 enum { GL_FAST_OP_STFT = 0, GL_FAST_OP_ISTFT = 1, GL_FAST_OP_RUN = 2 };
@@ -75,6 +78,9 @@ int gl_fast_run(gl_plan* p, const float* mag, const float* x0, float* x_out, int
 // ---- mel inversion (MFMA): gl_mel.hip ---------------------------------------------
 int gl_mel_launch(const float* fb, const float* mel, float* mag, int n_mels, int F, int B, int T, bool logmel,
                   float compression_factor, bool clamp, hipStream_t st);
+
+int gl_mag_to_logmel_launch(const float* fb, const float* mag, float* logmel, int n_mels, int F, int B, int T,
+                            float clip_min, float compression_factor, hipStream_t st);
 
 // ---- misc: gl_misc.hip -------------------------------------------------------------
 int gl_randn_launch(float* out, long long n, uint64_t seed, long long offset, hipStream_t st);

@@ -88,7 +88,69 @@ __global__ void __launch_bounds__(64 * kWaves) k_mel_to_mag(const float* __restr
     }
 }
 
+// N3  data.py:112-114: mel = filterbank @ |stft|, log(clip(mel, 0.01) * compression_factor).
+//     logmel[b][m][t] = log(max(sum_f fb[m][f] * mag[b][t][f], clip_min) * cf)
+// C[m x t] = A[m x f] * B[f x t] with i = m, j = t: the accumulator's 32 lanes of one register are 32
+// consecutive t of one mel band, so the (B, n_mels, T) output is stored coalesced.  One wave owns
+// 32 frames and all mel bands (kMelTiles accumulators of 32 bands); K = F runs two bins per MFMA.
+constexpr int kMelTiles = 4;     // up to 128 mel bands
+__global__ void __launch_bounds__(64 * kWaves) k_mag_to_logmel(const float* __restrict__ fb,
+                                                               const float* __restrict__ mag,
+                                                               float* __restrict__ logmel, int n_mels, int F, int T,
+                                                               float clip_min, float cf) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int t0 = (blockIdx.x * kWaves + wave) * 32;
+    if (t0 >= T) return;  // wave-uniform
+    const int li = lane & 31;
+    const int lk = lane >> 5;
+    const int t = t0 + li;
+    const bool t_ok = t < T;
+    const float* b_ptr = mag + ((long long)b * T + (t_ok ? t : 0)) * F;
+    const int tiles = (n_mels + 31) / 32;
+    f32x16 acc[kMelTiles];
+#pragma unroll
+    for (int j = 0; j < kMelTiles; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    for (int k0 = 0; k0 < F; k0 += 2) {
+        const int k = k0 + lk;
+        const bool k_ok = k < F;
+        const int kk = k_ok ? k : 0;
+        const float bv = (k_ok && t_ok) ? b_ptr[kk] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < kMelTiles; ++j) {
+            if (j < tiles) {
+                const int m = 32 * j + li;
+                const float av = (k_ok && m < n_mels) ? fb[(long long)m * F + kk] : 0.0f;
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
+            }
+        }
+    }
+    float* out = logmel + (long long)b * n_mels * T;
+    if (!t_ok) return;
+#pragma unroll
+    for (int j = 0; j < kMelTiles; ++j) {
+        if (j >= tiles) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = 32 * j + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            if (m < n_mels) out[(long long)m * T + t] = logf(fmaxf(acc[j][r], clip_min) * cf);
+        }
+    }
+}
+
 }  // namespace
+
+int gl_mag_to_logmel_launch(const float* fb, const float* mag, float* logmel, int n_mels, int F, int B, int T,
+                            float clip_min, float compression_factor, hipStream_t st) {
+    dim3 grid((T + 32 * kWaves - 1) / (32 * kWaves), B);
+    hipLaunchKernelGGL(k_mag_to_logmel, grid, dim3(64 * kWaves), 0, st, fb, mag, logmel, n_mels, F, T, clip_min,
+                       compression_factor);
+    GL_HIP_CHECK(hipGetLastError());
+    return 0;
+}
 
 int gl_mel_launch(const float* fb, const float* mel, float* mag, int n_mels, int F, int B, int T, bool logmel,
                   float compression_factor, bool clamp, hipStream_t st) {

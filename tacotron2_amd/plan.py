@@ -136,6 +136,21 @@ class Plan:
                                                   _stream_ptr(self.device)), "gl_logmel_to_mag")
         return out
 
+    def wav_to_logmel(self, y, filterbank, pad_mode="reflect", clip_min=0.01, compression_factor=1.0):
+        """y (B, len) -> (log-mel (B, n_mels, T), |stft| (B, T, F)), T = 1 + len // hop (data.py:110-114)."""
+        B, n = y.shape
+        n_mels = filterbank.shape[0]
+        T = int(self._lib.gl_analysis_num_frames(self.hop, n))
+        mag = torch.empty((B, T, self.n_bins), dtype=torch.float32, device=self.device)
+        logmel = torch.empty((B, n_mels, T), dtype=torch.float32, device=self.device)
+        mode = {"constant": 0, "reflect": 1}[pad_mode]
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.gl_wav_to_logmel(self._h, self._f32(y), n, n, self._f32(filterbank, (n_mels, self.n_bins)),
+                                                  self._f32(mag), self._f32(logmel), n_mels, mode, float(clip_min),
+                                                  float(compression_factor), B, _stream_ptr(self.device)),
+                       "gl_wav_to_logmel")
+        return logmel, mag
+
     def run(self, mag, x0, iterations, out=None, normalize=False, momentum=0.0):
         """mag (B, T, F), x0 (B, L) -> x (B, L) after `iterations` Griffin-Lim iterations.
         normalize / momentum: window-sum normalised ISTFT, fast Griffin-Lim (not in the reference)."""

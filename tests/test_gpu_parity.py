@@ -510,3 +510,47 @@ def test_variant_istft_normalised_inverts_stft_and_pinv_basis_clamps():
     want = np.maximum(0.0, filters.pinv_basis(fb).astype(np.float64) @ mel.astype(np.float64)).T
     assert np.max(np.abs(mag[0].cpu().numpy() - want)) <= 1e-5 * np.max(want)
     assert float(mag.min()) == 0.0
+
+
+# ---- N3: forward analysis path (data.py:100-116); librosa parity unpinned, numpy statement of its algorithm ----
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_fft,hop,n,pad", [(1024, None, 22050, "reflect"), (1024, None, 9000, "constant"),
+                                             (2048, 256, 30000, "reflect"), (1024, 275, 7777, "reflect")])
+def test_analysis_wav_to_logmel(n_fft, hop, n, pad):
+    from tacotron2_amd import analysis, filters
+    rng = np.random.default_rng(51)
+    tt = np.arange(n) / 22050.0
+    y = 0.4 * np.sin(2 * np.pi * 220 * tt) + 0.2 * np.sin(2 * np.pi * 3300 * tt) + 0.05 * rng.standard_normal(n)
+    y = np.clip(y, -1, 1).astype(np.float32)
+    yb = np.stack([y, y[::-1].copy()])
+    fb = filters.mel(22050, n_fft, 80, 125, 7600)
+    lm, mag = analysis.audio_to_mel(yb, n_fft=n_fft, hop=hop, filterbank=fb, pad_mode=pad, return_magnitude=True,
+                                    device="cuda:0")
+    h = n_fft // 4 if hop is None else hop
+    assert lm.shape == (2, 80, 1 + n // h) and mag.shape == (2, 1 + n // h, n_fft // 2 + 1)
+    for b in range(2):
+        ref_lm, ref_mag = orc.audio_to_logmel(yb[b], fb, n_fft, hop, pad)
+        assert np.max(np.abs(mag[b] - ref_mag)) <= 2e-5 * np.max(ref_mag)
+        # log of clipped values: absolute tolerance on the log, fp32 contraction over up to 1025 bins
+        assert np.max(np.abs(lm[b] - ref_lm)) <= 2e-4
+    one = analysis.audio_to_mel(y, n_fft=n_fft, hop=hop, filterbank=fb, pad_mode=pad, device="cuda:0")
+    assert one.shape == (80, 1 + n // h) and np.array_equal(one, lm[0])
+
+
+@pytest.mark.gpu
+def test_analysis_then_griffin_lim_round_trip():
+    """wav -> log-mel (N3) -> exp -> mel_to_audio (a-2): the reconstruction's own log-mel comes back close
+    to the input's (loose: Griffin-Lim with filterbank.T is not an inverse; this guards the plumbing:
+    layouts (80,T) <-> (T,F), hop 256 on both sides)."""
+    from tacotron2_amd import analysis, filters, griffin_lim as glm
+    n_fft, hop, n = 1024, 256, 22050
+    tt = np.arange(n) / 22050.0
+    y = (0.5 * np.sin(2 * np.pi * 440 * tt) * np.hanning(n)).astype(np.float32)
+    fb = filters.mel(22050, n_fft, 80, 125, 7600)
+    lm = analysis.audio_to_mel(y, n_fft=n_fft, hop=hop, filterbank=fb, device="cuda:0")
+    x, _ = glm.mel_to_audio(np.exp(lm), basis=filters.pinv_basis(fb), n_fft=n_fft, hop=hop, iterations=30, seed=3,
+                            normalize="peak", window_sum_normalize=True, device="cuda:0")
+    x = x[0].cpu().numpy()
+    lm2 = analysis.audio_to_mel(x[:n], n_fft=n_fft, hop=hop, filterbank=fb, device="cuda:0")
+    band = int(np.argmax(lm.mean(axis=1)))
+    assert int(np.argmax(lm2.mean(axis=1))) in (band - 1, band, band + 1)      # the 440 Hz band is still the loudest

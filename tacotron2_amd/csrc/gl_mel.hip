@@ -29,12 +29,22 @@ template <bool LOGMEL>
 __global__ void __launch_bounds__(64 * kWaves) k_mel_to_mag(const float* __restrict__ fb,
                                                             const float* __restrict__ mel,
                                                             float* __restrict__ mag, int K, int F, int T,
-                                                            float inv_cf, float floor_val) {
+                                                            float inv_cf, float floor_val, int n_ftiles,
+                                                            int n_tblocks, int n_groups) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int b = blockIdx.z;
-    const int t0 = (blockIdx.y * kWaves + wave) * kTileT;
-    const int f0 = blockIdx.x * kTileF;
+    // XCD-aware tile order.  Workgroups go to the 8 XCDs round-robin by linear id, and a 128-byte
+    // store into the 4100-byte rows rarely covers a whole cache line: the F-tiles that share lines
+    // (same utterance, same frames) are given ids with equal id % 8, so they run on one XCD and
+    // their partial lines merge in that XCD's L2 instead of leaving as partial writes from several.
+    const int id = blockIdx.x;
+    const int q = id >> 3;
+    const int ft = q % n_ftiles;
+    const int g = (q / n_ftiles) * 8 + (id & 7);        // (utterance, frame block)
+    if (g >= n_groups) return;                          // padding of the last group of eight
+    const int b = g / n_tblocks;
+    const int t0 = ((g - b * n_tblocks) * kWaves + wave) * kTileT;
+    const int f0 = ft * kTileF;
     if (t0 >= T) return;  // wave-uniform
 
     const int li = lane & 31;
@@ -59,6 +69,7 @@ __global__ void __launch_bounds__(64 * kWaves) k_mel_to_mag(const float* __restr
         fidx[j] = f_ok[j] ? f : 0;
     }
 
+#pragma unroll 8      // eight K-steps of loads in flight ahead of their MFMAs
     for (int k0 = 0; k0 < K; k0 += 2) {
         const int k = k0 + lk;
         const bool k_ok = k < K;
@@ -155,13 +166,16 @@ int gl_mag_to_logmel_launch(const float* fb, const float* mag, float* logmel, in
 int gl_mel_launch(const float* fb, const float* mel, float* mag, int n_mels, int F, int B, int T, bool logmel,
                   float compression_factor, bool clamp, hipStream_t st) {
     const float floor_val = clamp ? 0.0f : -INFINITY;     // GL_OPT_CLAMP_MAG (pseudo-inverse bases go negative)
-    dim3 grid((F + kTileF - 1) / kTileF, (T + kTileT * kWaves - 1) / (kTileT * kWaves), B);
+    const int n_ftiles = (F + kTileF - 1) / kTileF;
+    const int n_tblocks = (T + kTileT * kWaves - 1) / (kTileT * kWaves);
+    const int n_groups = n_tblocks * B;
+    dim3 grid((unsigned)(((n_groups + 7) / 8) * 8 * n_ftiles));
     if (logmel)
         hipLaunchKernelGGL(k_mel_to_mag<true>, grid, dim3(64 * kWaves), 0, st, fb, mel, mag, n_mels, F, T,
-                           1.0f / compression_factor, floor_val);
+                           1.0f / compression_factor, floor_val, n_ftiles, n_tblocks, n_groups);
     else
         hipLaunchKernelGGL(k_mel_to_mag<false>, grid, dim3(64 * kWaves), 0, st, fb, mel, mag, n_mels, F, T, 1.0f,
-                           floor_val);
+                           floor_val, n_ftiles, n_tblocks, n_groups);
     GL_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -117,6 +117,13 @@ int gl_wav_to_logmel(gl_plan* plan, const float* y, long long y_stride, long lon
 int gl_run(gl_plan* plan, const float* mag, const float* x0, float* x_out,
            int iters, int B, int T, void* stream);
 
+/* Ragged batches.  The reference reconstructs one utterance per call (audio_utilities.py:154), so
+ * utterances of different lengths never meet; a batch here has one frame count T for all.  Zeroing
+ * the magnitude rows t >= frames[b] makes the padding frames project to exactly zero (they add
+ * nothing to the overlap-add), so gl_run on the padded batch gives utterance b the samples
+ * [0, frames[b]*H + N) it would get alone and zeros after them.  frames : [B] int32 on the device.   */
+int gl_mask_frames(gl_plan* plan, float* mag, const int* frames, int B, int T, void* stream);
+
 /* Select the code path gl_run / gl_stft / gl_istft use: 0 = auto (fused
  * wave-per-frame kernels where the geometry has one, else generic),
  * 1 = force the generic (any power-of-two N) kernels.  For tests/benchmarks.   */

@@ -44,6 +44,7 @@ SIGNATURES = {
     "gl_graph_end": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]),
     "gl_graph_launch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "gl_graph_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "gl_mask_frames": (ctypes.c_int, [_plan_p, _c_float_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "gl_randn": (ctypes.c_int, [_c_float_p, ctypes.c_longlong, ctypes.c_uint64, ctypes.c_void_p]),
     "gl_randn_at": (ctypes.c_int, [_c_float_p, ctypes.c_longlong, ctypes.c_uint64, ctypes.c_longlong, ctypes.c_void_p]),
     "gl_stitch_add": (ctypes.c_int, [_c_float_p, ctypes.c_longlong, _c_float_p, ctypes.c_longlong, ctypes.c_longlong,

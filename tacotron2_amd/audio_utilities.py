@@ -149,6 +149,12 @@ def istft_for_reconstruction(X, fft_size, hopsamp, *, normalize=False, device=No
     return y
 
 
+def _zero_past(x, lengths, hop, n_fft):
+    """Samples past an utterance's own length (lengths[b]*hop + n_fft) are padding: exact zeros."""
+    for b, t in enumerate(lengths):
+        x[b, int(t) * hop + n_fft:].zero_()
+
+
 # -- a-3 / a-6 ---------------------------------------------------------------------------------
 def _start_signal(B, L, x_init, seed, rng, plan, dev):
     if x_init is not None:
@@ -171,14 +177,16 @@ def _start_signal(B, L, x_init, seed, rng, plan, dev):
 
 def reconstruct_signal_griffin_lim(magnitude_spectrogram, fft_size, hopsamp, iterations, *,
                                    x_init=None, seed=None, rng="numpy", device=None, normalize=False,
-                                   momentum=0.0):
+                                   momentum=0.0, lengths=None):
     """Griffin-Lim reconstruction (audio_utilities.py:154-188).
 
     magnitude_spectrogram: (T, F) or (B, T, F), rows = time slices.  The whole
     loop (STFT -> keep phase, impose magnitude -> ISTFT) runs on the GPU on the
     current HIP stream.  Returns (T*hopsamp + fft_size,) [or (B, ...)].
     normalize / momentum (both off = the reference): window-sum normalised inverse STFT in every
-    iteration; fast Griffin-Lim extrapolation x_n + momentum (x_n - x_{n-1})."""
+    iteration; fast Griffin-Lim extrapolation x_n + momentum (x_n - x_{n-1}).
+    lengths: frames per utterance of a ragged batch (B,); rows beyond them are ignored and utterance b
+    comes out as it would alone with lengths[b] frames, followed by zeros (see gl_mask_frames)."""
     fft_size, hopsamp, iterations = int(fft_size), int(hopsamp), int(iterations)
     dev = _pick_device(device, magnitude_spectrogram, x_init)
     mag, was_np = _to_device(magnitude_spectrogram, dev, torch.float32)
@@ -194,8 +202,17 @@ def reconstruct_signal_griffin_lim(magnitude_spectrogram, fft_size, hopsamp, ite
         raise ValueError("need at least one frame")
     L = T * hopsamp + fft_size
     plan = get_plan(fft_size, hopsamp, T, B, dev)
+    if lengths is not None and normalize:
+        raise ValueError("normalize=True needs the window sum of each utterance's own length: run ragged "
+                         "batches without it or one length at a time")
+    if lengths is not None:
+        if mag.data_ptr() == getattr(magnitude_spectrogram, "data_ptr", lambda: 0)():
+            mag = mag.clone()            # never modify the caller's tensor
+        plan.mask_frames(mag, lengths)
     x0 = _start_signal(B, L, x_init, seed, rng, plan, dev)
     x = plan.run(mag, x0, iterations, out=x0, normalize=normalize, momentum=momentum)
+    if lengths is not None:
+        _zero_past(x, lengths, hopsamp, fft_size)
     if single:
         x = x[0]
     if was_np:

@@ -335,6 +335,14 @@ int gl_graph_destroy(gl_graph* g) {
     return 0;
 }
 
+int gl_mask_frames(gl_plan* p, float* mag, const int* frames, int B, int T, void* stream) {
+    int rc = check_call(p, B, T, "gl_mask_frames");
+    if (rc) return rc;
+    if (!mag || !frames) return gl_set_error(GL_ERR_INVALID, "gl_mask_frames: NULL buffer");
+    DeviceGuard guard(p->device);
+    return gl_mask_launch(mag, frames, B, T, p->n_fft / 2 + 1, (hipStream_t)stream);
+}
+
 int gl_randn(float* out, long long n, uint64_t seed, void* stream) {
     if (!out || n < 0) return gl_set_error(GL_ERR_INVALID, "gl_randn: bad argument");
     if (n == 0) return 0;

@@ -88,6 +88,7 @@ int gl_stitch_launch(float* out, long long out_len, const float* chunk, long lon
                      long long fade_in, long long fade_out, hipStream_t st);
 int gl_peak_launch(gl_plan* p, float* x, long long row_stride, long long len, float* peaks, int mode, int B,
                    hipStream_t st);
+int gl_mask_launch(float* mag, const int* frames, int B, int T, int F, hipStream_t st);
 int gl_copy_rows(float* dst, const float* src, long long n, hipStream_t st);
 int gl_pcm16_launch(gl_plan* p, const float* x, long long row_stride, long long len, int16_t* pcm,
                     long long pcm_stride, float* peaks, int B, hipStream_t st);

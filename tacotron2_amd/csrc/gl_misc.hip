@@ -128,7 +128,26 @@ __global__ void __launch_bounds__(kThreads) k_pcm16(const float* __restrict__ x,
     }
 }
 
+// Ragged batches: rows t >= frames[b] of mag[b] are zeroed.  A zero magnitude row projects to an exactly
+// zero frame (X * (0 * rsq) = 0 and the zero-bin rule gives (mag, 0) = 0), which adds nothing to the
+// overlap-add, so utterance b comes out as if it had been run alone with frames[b] frames.
+__global__ void __launch_bounds__(kThreads) k_mask_frames(float* __restrict__ mag, const int* __restrict__ frames,
+                                                          int T, int F) {
+    const int b = blockIdx.y;
+    const int tb = min(max(frames[b], 0), T);
+    const long long n = (long long)(T - tb) * F;
+    float* base = mag + ((long long)b * T + tb) * F;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        base[i] = 0.0f;
+}
+
 }  // namespace
+
+int gl_mask_launch(float* mag, const int* frames, int B, int T, int F, hipStream_t st) {
+    hipLaunchKernelGGL(k_mask_frames, dim3(64, B), dim3(kThreads), 0, st, mag, frames, T, F);
+    GL_HIP_CHECK(hipGetLastError());
+    return 0;
+}
 
 int gl_pcm16_launch(gl_plan* p, const float* x, long long row_stride, long long len, int16_t* pcm,
                     long long pcm_stride, float* peaks, int B, hipStream_t st) {

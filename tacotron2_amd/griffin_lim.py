@@ -45,14 +45,16 @@ def _device_filterbank(fb, dev):
 
 
 def mel_to_audio(mel_spectrogram, *, basis=None, n_fft=None, hop=None, iterations=None, x_init=None, seed=None,
-                 rng="numpy", normalize="reference", device=None, window_sum_normalize=False, momentum=0.0):
+                 rng="numpy", normalize="reference", device=None, window_sum_normalize=False, momentum=0.0,
+                 lengths=None):
     """Batched core of save_mel_to_wav, everything on the GPU.
 
     mel_spectrogram: (n_mels, T) or (B, n_mels, T), numpy or torch (linear-amplitude
     mel, i.e. after exp, infer.py:27).  basis: (F, n_mels) inversion basis; default
     ``filterbank.T`` like griffin_lim.py:18; ``"pinv"`` = pseudo-inverse of the filterbank with the
     magnitudes clamped at 0 (north-star variant, not the reference).  window_sum_normalize /
-    momentum: see audio_utilities.reconstruct_signal_griffin_lim.  normalize: 'reference' (divide by the
+    momentum / lengths (ragged batch: frames per utterance): see
+    audio_utilities.reconstruct_signal_griffin_lim.  normalize: 'reference' (divide by the
     peak only when it exceeds 1, griffin_lim.py:27-29), 'peak' (always) or None.
     Returns (waveforms (B, L) fp32 torch on device, magnitude (B, T, F) fp32 torch)."""
     n_fft = int(params.n_fft if n_fft is None else n_fft)
@@ -87,9 +89,15 @@ def mel_to_audio(mel_spectrogram, *, basis=None, n_fft=None, hop=None, iteration
                          f"({n_mels}, {n_fft // 2 + 1})")
     plan = get_plan(n_fft, hop, T, B, dev)
     mag = plan.mel_to_mag(fb_dev, mel, clamp=clamp)          # griffin_lim.py:18-19
+    if lengths is not None:
+        if window_sum_normalize:
+            raise ValueError("window_sum_normalize needs each utterance's own window sum: not with lengths=")
+        plan.mask_frames(mag, lengths)
     L = plan.signal_length(T)
     x0 = audio_utilities._start_signal(B, L, x_init, seed, rng, plan, dev)
     x = plan.run(mag, x0, iterations, out=x0, normalize=window_sum_normalize, momentum=momentum)   # :23-24
+    if lengths is not None:
+        audio_utilities._zero_past(x, lengths, hop, n_fft)
     if normalize == "reference":
         plan.peak_normalise(x, mode=0)                       # griffin_lim.py:27-29
     elif normalize == "peak":
@@ -100,7 +108,7 @@ def mel_to_audio(mel_spectrogram, *, basis=None, n_fft=None, hop=None, iteration
 
 
 def logmel_to_audio(y_pred_post, *, compression_factor=1.0, basis=None, n_fft=None, hop=None, iterations=None,
-                    x_init=None, seed=None, rng="numpy", normalize="reference", device=None):
+                    x_init=None, seed=None, rng="numpy", normalize="reference", device=None, lengths=None):
     """infer.py:24-29 without the host round trip: the decoder output goes in as it is.
 
     y_pred_post: (B, T, n_mels) or (T, n_mels) natural-log mel (Tacotron2.inference's second
@@ -133,9 +141,13 @@ def logmel_to_audio(y_pred_post, *, compression_factor=1.0, basis=None, n_fft=No
                          f"({n_mels}, {n_fft // 2 + 1})")
     plan = get_plan(n_fft, hop, T, B, dev)
     mag = plan.logmel_to_mag(fb_dev, lm, compression_factor)
+    if lengths is not None:                 # ragged batch: decoder frames past an utterance's end are ignored
+        plan.mask_frames(mag, lengths)
     L = plan.signal_length(T)
     x0 = audio_utilities._start_signal(B, L, x_init, seed, rng, plan, dev)
     x = plan.run(mag, x0, iterations, out=x0)
+    if lengths is not None:
+        audio_utilities._zero_past(x, lengths, hop, n_fft)
     if normalize == "reference":
         plan.peak_normalise(x, mode=0)
     elif normalize == "peak":

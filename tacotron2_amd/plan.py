@@ -151,6 +151,18 @@ class Plan:
                        "gl_wav_to_logmel")
         return logmel, mag
 
+    def mask_frames(self, mag, lengths):
+        """Zero the rows t >= lengths[b] of mag (B, T, F) in place (ragged batches); returns the
+        device int32 tensor of lengths."""
+        B, T, _ = mag.shape
+        lens = torch.as_tensor(lengths, dtype=torch.int32).to(self.device).contiguous()
+        if tuple(lens.shape) != (B,):
+            raise ValueError(f"lengths must have shape ({B},)")
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.gl_mask_frames(self._h, self._f32(mag), ctypes.c_void_p(lens.data_ptr()), B, T,
+                                                _stream_ptr(self.device)), "gl_mask_frames")
+        return lens
+
     def run(self, mag, x0, iterations, out=None, normalize=False, momentum=0.0):
         """mag (B, T, F), x0 (B, L) -> x (B, L) after `iterations` Griffin-Lim iterations.
         normalize / momentum: window-sum normalised ISTFT, fast Griffin-Lim (not in the reference)."""

@@ -487,12 +487,15 @@ __device__ __forceinline__ void lds_wr_pair(v2f* q, v2f a, v2f b) {
 }
 
 constexpr int kT2Win = 0;       // 16: (w[2(l+64j)], w[2(l+64j)+1])
-constexpr int kT2WinSc = 16;    // 16: the same / 1024
-constexpr int kT2Tw1 = 32;      // 15: W1024^(l*k2), k2 = 1..15
-constexpr int kT2Tw2 = 48;      // 7:  W64^(a*d), d = 1..7   (every group starts on an even entry: pair reads)
-constexpr int kT2Twp = 56;      // 9:  -i * W2048^(kP[u])
-constexpr int kT2Entries = 66;   // entries copied to LDS (33 KB)
-constexpr int kT2Zero = 66;      // global-only: one row of zeros after the table (the "no tail" operand of load_row)
+constexpr int kT2Tw1 = 16;      // 15: W1024^(l*k2), k2 = 1..15     (every group starts on an even entry: pair reads)
+constexpr int kT2Tw2 = 32;      // 7:  W64^(a*d), d = 1..7
+constexpr int kT2Twp = 40;      // 9:  -i * W2048^(kP[u])
+constexpr int kT2A16F = 50;     // 8:  the lane's 16 coefficients of the forward DFT-16 matrix (dft16_mfma)
+constexpr int kT2A16I = 58;     // 8:  ... of the inverse
+constexpr int kT2Entries = 66;   // entries the register-ring kernel copies to LDS (33 KB)
+constexpr int kT2WinSc = 66;    // 16: the window / 1024 (n_fft-1024 kernel only; the 2048 kernel folds its scale into the magnitudes)
+constexpr int kT2EntriesPair = 82;   // entries the n_fft-1024 kernel copies
+constexpr int kT2Zero = 82;      // global-only: one row of zeros after the table (the "no tail" operand of load_row)
 // Entries are stored in pairs, [e/2][lane][e&1]: a lane's entries 2p and 2p+1 are 16 contiguous bytes, so
 // constants that are used together (two window values, two twiddles) arrive with one ds_read_b128
 // (full LDS rate) instead of two reads.  tabl = smem + 2*lane; entry e of the lane is tabl[TE(e)].
@@ -537,6 +540,59 @@ struct Stamps {
 };
 #endif
 
+// DFT-16 on the matrix cores.  The butterflies above cost 78 packed VALU operations per call and the fused
+// kernels are bound by VALU issue while the MFMA pipe idles, so the radix-16 pass is also available as a dense
+// real product C[32 x 64] = A[32 x 32] * B[32 x 64] on v_mfma_f32_32x32x2_f32 (exact fp32 fma chains of 16
+// terms): B row 2s / 2s+1 = re / im of input s (a lane's column is its own 16 inputs), A = the DFT matrix
+// with output row i = component i&1 of output k2 = i>>1 (per-lane coefficients from the table).  One
+// v_permlane32_swap per input turns (re, im) of the two lane halves into the B operands of the two 32-column
+// blocks; one per accumulator register afterwards gives every lane all 32 rows of its own column, already as
+// (re, im) register pairs.  32 MFMAs + 32 swaps + 4 table reads replace the 78 packed operations.
+// MEASURED AND REJECTED (kept for the record, -DGL_MFMA16=1, parity-green): 0.226 ms per iteration against
+// 0.155 ms with the butterflies on config 2 -- 64 dependent fp32 MFMAs per frame (2 chains of 16 per call,
+// 64 cycles each) cost a wave more than the 156 packed operations they replace.
+#ifndef GL_MFMA16
+#define GL_MFMA16 0
+#endif
+typedef float f32x16_ __attribute__((ext_vector_type(16)));
+template <bool INV>
+__device__ __forceinline__ void dft16_mfma(v2f* z, const v2f* __restrict__ tabl) {
+    f32x16_ c0, c1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { c0[r] = 0.0f; c1[r] = 0.0f; }
+#pragma unroll
+    for (int sp = 0; sp < 4; ++sp) {
+        v2f a01, a23;
+        lds_rd_pair(&tabl[TE((INV ? kT2A16I : kT2A16F) + 2 * sp)], a01, a23);
+        const float av[4] = {a01.x, a01.y, a23.x, a23.y};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int s = 4 * sp + q;
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(z[s].x), __float_as_uint(z[s].y), false, false);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], __uint_as_float(sw[0]), c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], __uint_as_float(sw[1]), c1, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(c0[r]), __float_as_uint(c1[r]), false, false);
+        c0[r] = __uint_as_float(sw[0]);
+        c1[r] = __uint_as_float(sw[1]);
+    }
+    // accumulator register r of a lane now holds row (r&3) + 8(r>>2) (c0) / that + 4 (c1) of the lane's column
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int k2 = (q & 1) + 4 * (q >> 1);
+        z[k2] = (v2f){c0[2 * q], c0[2 * q + 1]};
+        z[k2 + 2] = (v2f){c1[2 * q], c1[2 * q + 1]};
+    }
+}
+template <bool INV>
+__device__ __forceinline__ void dft16_any(v2f* z, const v2f* __restrict__ tabl) {
+    if (GL_MFMA16) dft16_mfma<INV>(z, tabl);
+    else dft16<INV>(z);
+}
+
 #ifndef GL_TW2_REG
 #define GL_TW2_REG 0   // 1: the seven W64 twiddles live in registers (callers pass them) instead of LDS reads
 #endif
@@ -545,7 +601,7 @@ __device__ __forceinline__ void fft_forward_1024(v2f* z, v2f* ex, int l, int a3,
     const int piL = a3 * kE1P + g3;                                    // pi(l)
     const int rhoL = (l & 15) * kE2Q + (l >> 4);                       // rho(l)
     const int rhoK = (kloB & 15) * kE2Q + (kloB >> 4);                 // rho(128 - l) (lane 0: rho(64))
-    dft16<false>(z);
+    dft16_any<false>(z, tabl);
 #pragma unroll
     for (int pp = 0; pp < 7; ++pp) {
         v2f wa, wb;
@@ -664,7 +720,7 @@ __device__ __forceinline__ void fft_inverse_1024(v2f* z, v2f* ex, int l, int a3,
         z[2 * pp + 2] = cmulc(z[2 * pp + 2], wb);
     }
     z[15] = cmulc(z[15], lds_rd(&tabl[TE(kT2Tw1 + 14)]));
-    dft16<true>(z);
+    dft16_any<true>(z, tabl);
     st.mark(11);
 }
 
@@ -721,6 +777,9 @@ __device__ __forceinline__ void middle_project(v2f* z, bool l0, const float* m_l
 // [frame][quad q][lane][4] + [frame][1024 + lane]: four aligned dwordx4 loads and one dword per
 // frame, 34 line requests instead of about 51.  4352 bytes per frame (6 % more than 4100).
 constexpr int kMagPack = 1088;
+// 1/M of the inverse transform and the factor 2 the split step leaves, folded into the magnitudes once
+// (a power of two: exact), so the forward and the inverse window are the same table entries
+constexpr float kMagScale = 1.0f / (2.0f * kM);
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 __global__ void __launch_bounds__(64) k_mag_repack(const float* __restrict__ mag, float* __restrict__ out, int T) {
@@ -733,13 +792,13 @@ __global__ void __launch_bounds__(64) k_mag_repack(const float* __restrict__ mag
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const int k = (u < 4 ? bA : bB) + 128 * u;
-        v[u] = mrow[k];
-        v[8 + u] = mrow[kM - k];
+        v[u] = mrow[k] * kMagScale;
+        v[8 + u] = mrow[kM - k] * kMagScale;
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q)
         *reinterpret_cast<v4f*>(orow + (q * 64 + l) * 4) = (v4f){v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
-    orow[1024 + l] = mrow[512];
+    orow[1024 + l] = mrow[512] * kMagScale;
 }
 
 struct AlignedArgs {
@@ -905,7 +964,7 @@ __global__ void __launch_bounds__(64 * kRRWaves, GL_RR_OCC) k_gl2048_regring(Ali
         fft_inverse_1024(z, ex, l, a3, g3, kloB, tabl, st, w2r);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            v2f w = lds_rd(&tabl[TE(kT2WinSc + j)]);
+            v2f w = lds_rd(&tabl[TE(kT2Win + j)]);      // 1/2048 is folded into the packed magnitudes
             accr[j].x = fmaf(z[j].x, w.x, accr[j].x);
             accr[j].y = fmaf(z[j].y, w.y, accr[j].y);
         }
@@ -1010,15 +1069,15 @@ __device__ __forceinline__ void middle_two_frames(v2f* z, bool l0, const float* 
 
 __global__ void __launch_bounds__(64 * kP1Waves, 1) k_gl1024_pair(Pair1024Args p) {
     // table 32 KB + 4 x (9 KB transpose scratch + 8 KB x ring + 8 KB accumulator ring) = 132 KB
-    __shared__ __attribute__((aligned(16))) v2f smem[kT2Entries * 64 + kP1Waves * kP1WaveLds];
+    __shared__ __attribute__((aligned(16))) v2f smem[kT2EntriesPair * 64 + kP1Waves * kP1WaveLds];
     const int l = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.y;
     const int run = blockIdx.x * kP1Waves + wave;
-    for (int i = threadIdx.x; i < kT2Entries * 64; i += 64 * kP1Waves) smem[i] = p.tab[i];
+    for (int i = threadIdx.x; i < kT2EntriesPair * 64; i += 64 * kP1Waves) smem[i] = p.tab[i];
     __syncthreads();
     if (run >= p.nruns) return;                  // wave-uniform; no barrier after this point
-    v2f* ex = smem + kT2Entries * 64 + wave * kP1WaveLds;
+    v2f* ex = smem + kT2EntriesPair * 64 + wave * kP1WaveLds;
     float* xring = reinterpret_cast<float*>(ex + kRScratch);
     float* acc = xring + kP1Ring;
     const v2f* tabl = smem + 2 * l;
@@ -1267,7 +1326,7 @@ int fold(gl_plan* p, const float* x_main, const float* tail, float* x_out, int B
 int ensure_table2(gl_plan* p) {
     if (p->d_fast_tab2) return 0;
     const int N = p->n_fft;
-    std::vector<float> tab((size_t)(kT2Entries + 1) * 64 * 2, 0.0f);
+    std::vector<float> tab((size_t)(kT2Zero + 1) * 64 * 2, 0.0f);
     const double pi = 3.14159265358979323846;
     auto put = [&](int e, int l, double re, double im) {      // pair layout, see TE()
         const size_t at = ((size_t)(e >> 1) * 128 + 2 * (size_t)l + (e & 1)) * 2;
@@ -1285,15 +1344,28 @@ int ensure_table2(gl_plan* p) {
             float w0 = (float)(0.5 - 0.5 * cos(2.0 * pi * n0 / (double)(N - 1)));
             float w1 = (float)(0.5 - 0.5 * cos(2.0 * pi * n1 / (double)(N - 1)));
             put(kT2Win + j, l, w0, w1);
-            // 1/M of the inverse transform; the 2048 kernel's split step leaves another factor 2
-            const double sc = (N == kN) ? 2.0 * kM : (double)kM;
-            put(kT2WinSc + j, l, (double)w0 / sc, (double)w1 / sc);   // exact: power-of-two scale
+            put(kT2WinSc + j, l, (double)w0 / kM, (double)w1 / kM);   // exact: power-of-two scale (n_fft 1024)
         }
         for (int k2 = 1; k2 < 16; ++k2) put(kT2Tw1 + k2 - 1, l, Wre(1024, (long long)l * k2), Wim(1024, (long long)l * k2));
         for (int d = 1; d < 8; ++d) put(kT2Tw2 + d - 1, l, Wre(64, (long long)(l & 7) * d), Wim(64, (long long)(l & 7) * d));
         for (int u = 0; u < 9; ++u) {
             int k = (u == 8) ? 512 : (l ? l + 128 * u : (u < 4 ? 128 * u : 64 + 128 * (u - 4)));
             put(kT2Twp + u, l, Wim(2048, k), -Wre(2048, k));   // -i * W2048^k (middle_project)
+        }
+        // DFT-16 as a 32x32 real matrix (dft16_mfma): lane (i = l&31, kk = l>>5) supplies A[i][2s+kk] for the
+        // K-step s = input index; output row i is component i&1 (re, im) of output k2 = i>>1
+        {
+            const int i = l & 31, kk = l >> 5, k2 = i >> 1, comp = i & 1;
+            for (int s2 = 0; s2 < 16; ++s2) {
+                const double th = 2.0 * pi * (double)((s2 * k2) % 16) / 16.0;
+                const double c = cos(th), sn = sin(th);
+                // forward e^{-i th}: re' = c re + sn im, im' = -sn re + c im; inverse e^{+i th}: signs of sn flipped
+                const double af = comp == 0 ? (kk == 0 ? c : sn) : (kk == 0 ? -sn : c);
+                const double ai = comp == 0 ? (kk == 0 ? c : -sn) : (kk == 0 ? sn : c);
+                const size_t ef = kT2A16F + s2 / 2, ei = kT2A16I + s2 / 2;
+                tab[((size_t)(ef >> 1) * 128 + 2 * (size_t)l + (ef & 1)) * 2 + (s2 & 1)] = (float)af;
+                tab[((size_t)(ei >> 1) * 128 + 2 * (size_t)l + (ei & 1)) * 2 + (s2 & 1)] = (float)ai;
+            }
         }
     }
     int rc = gl_plan_alloc(p, (void**)&p->d_fast_tab2, tab.size() * sizeof(float));

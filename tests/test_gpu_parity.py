@@ -332,7 +332,7 @@ def test_config5_geometry_batch32():
     assert torch.isfinite(y).all() and torch.all(y[:, -H:] == 0)
     # automatic run length depends on the batch size: rows agree to rounding ...
     y7 = p.run(mag[7:8].contiguous(), x0[7:8].contiguous(), K)
-    assert peak_err(y7[0].cpu().numpy(), y[7].cpu().numpy()) <= 1e-4
+    assert peak_err(y7[0].cpu().numpy(), y[7].cpu().numpy()) <= 3e-4     # 60 iterations amplify the seams' rounding
     # ... and bit for bit once the run length is pinned (what a sharded multi-GPU job does)
     p.set_run_frames(32)
     yp = p.run(mag, x0, K)

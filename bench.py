@@ -92,8 +92,14 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # BENCH_BACKEND=gloo rehearses the N>1 path on a box with fewer GPUs than ranks (ranks share cards)
+        backend = os.environ.get("BENCH_BACKEND", "nccl")
+        local_dev = local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(local_dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_dev))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     n_gpus = world if world > 1 else 1
@@ -143,7 +149,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -166,7 +172,7 @@ def main():
         barrier()
         graph_ms = (time.perf_counter() - tg) / args.steps * 1e3
         if dist is not None:
-            t = torch.tensor([graph_ms], dtype=torch.float64, device=dev)
+            t = torch.tensor([graph_ms], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             graph_ms = float(t.item())
         assert torch.equal(x, x_stream), "graph replay differs from the stream-launched step"

@@ -727,17 +727,47 @@ __device__ __forceinline__ void fft_inverse_1024(v2f* z, v2f* ex, int l, int a3,
 // rfft split + magnitude projection + inverse split on the 9 lane-local mirror pairs.
 // lanes >= 1: P[c] = A[c], Q[c] = B[7-c]; lane 0 pairs inside its own two butterflies
 // (oracle/sim_fast2048.py); unit 8 is lane 0's self-mirrored bin 512 (a dummy elsewhere).
+// Lane 0 owns the two self-mirrored butterflies (k_lo = 0 and 64), so its nine units pair registers differently
+// from every other lane's.  Instead of 24 two-instruction selects per frame, the twelve registers that differ
+// are rotated for lane 0 alone: twelve v_mov_b64 under EXEC = lane 0, in an order that needs no temporary
+// (the wave runs with all 64 lanes enabled: the kernels have no divergent control flow around this point).
+#ifndef GL_L0_MOV
+#define GL_L0_MOV 1
+#endif
+// d0 <- d1 <- ... <- d11 <- src   (for lane 0 only)
+__device__ __forceinline__ void lane0_chain(v2f& d0, v2f& d1, v2f& d2, v2f& d3, v2f& d4, v2f& d5, v2f& d6, v2f& d7,
+                                            v2f& d8, v2f& d9, v2f& d10, v2f& d11, v2f src) {
+    asm("s_mov_b64 exec, 1\n\t"
+        "v_mov_b64 %0, %1\n\tv_mov_b64 %1, %2\n\tv_mov_b64 %2, %3\n\tv_mov_b64 %3, %4\n\t"
+        "v_mov_b64 %4, %5\n\tv_mov_b64 %5, %6\n\tv_mov_b64 %6, %7\n\tv_mov_b64 %7, %8\n\t"
+        "v_mov_b64 %8, %9\n\tv_mov_b64 %9, %10\n\tv_mov_b64 %10, %11\n\tv_mov_b64 %11, %12\n\t"
+        "s_mov_b64 exec, -1"
+        : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7), "+v"(d8), "+v"(d9),
+          "+v"(d10), "+v"(d11)
+        : "v"(src));
+}
+
+// rfft split + magnitude projection + inverse split on the 9 lane-local mirror pairs.
+// lanes >= 1: P[c] = A[c], Q[c] = B[7-c]; lane 0 pairs inside its own two butterflies
+// (oracle/sim_fast2048.py); unit 8 is lane 0's self-mirrored bin 512 (a dummy elsewhere).
 __device__ __forceinline__ void middle_project(v2f* z, bool l0, const float* m_lo, const float* m_hi,
                                                const v2f* __restrict__ tabl) {
     v2f P[9], Q[9];
+    const v2f z4 = z[4];
+#if GL_L0_MOV
+    // lane 0: P[4..7] = z[8..11], Q[0] = z[0], Q[1..3] = z[7..5], Q[4..7] = z[15..12]; with P[c] living in z[c]
+    // and Q[c] in z[15-c] that is the rotation z4<-z8<-z12<-z5<-z9<-z13<-z6<-z10<-z14<-z7<-z11<-z15<-z0
+    lane0_chain(z[4], z[8], z[12], z[5], z[9], z[13], z[6], z[10], z[14], z[7], z[11], z[15], z[0]);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { P[c] = z[c]; Q[c] = z[15 - c]; }
+#else
     P[0] = z[0];
     Q[0] = sel(l0, z[0], z[15]);
 #pragma unroll
     for (int c = 1; c < 4; ++c) { P[c] = z[c]; Q[c] = sel(l0, z[8 - c], z[15 - c]); }
 #pragma unroll
     for (int c = 4; c < 8; ++c) { P[c] = sel(l0, z[8 + c - 4], z[c]); Q[c] = sel(l0, z[8 + 11 - c], z[15 - c]); }
-    P[8] = z[4];
-    Q[8] = z[4];
+#endif
     // w = -i*W2048^k.  2X[k] = (P + conj Q) + w*(P - conj Q), 2conj(X[M-k]) = the same with -w;
     // the projection is scale-free and commutes with conj; back: 2z[k] = (X+Y) + (X-Y)*conj(w),
     // 2z[M-k] = conj((X+Y) - (X-Y)*conj(w)).  The factor 2 is folded into the scaled window.
@@ -756,7 +786,15 @@ __device__ __forceinline__ void middle_project(v2f* z, bool l0, const float* m_l
         unit(2 * pp, wa);
         unit(2 * pp + 1, wb);
     }
-    unit(8, lds_rd(&tabl[TE(kT2Twp + 8)]));
+    // unit 8 = lane 0's bin 512, its own mirror (w = -1): the general formula collapses to 2 * project(z, m)
+    P[8] = project(z4, m_lo[8] + m_lo[8]);
+#if GL_L0_MOV
+    // results live in R_c = P[c] (-> z[c]) and S_i = Q[7-i] (-> z[8+i]); lane 0 wants z4 = P8, z5..7 = Q3..1,
+    // z8..11 = P4..7, z12..15 = Q7..4: the rotation S7<-S3<-R7<-S6<-S2<-R6<-S5<-S1<-R5<-S4<-S0<-R4<-P8
+    lane0_chain(Q[0], Q[4], P[7], Q[1], Q[5], P[6], Q[2], Q[6], P[5], Q[3], Q[7], P[4], P[8]);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { z[c] = P[c]; z[8 + c] = Q[7 - c]; }
+#else
     z[0] = P[0];
 #pragma unroll
     for (int c = 1; c < 4; ++c) z[c] = P[c];
@@ -767,6 +805,7 @@ __device__ __forceinline__ void middle_project(v2f* z, bool l0, const float* m_l
     for (int i = 0; i < 4; ++i) z[8 + i] = sel(l0, P[4 + i], Q[7 - i]);
 #pragma unroll
     for (int i = 4; i < 8; ++i) z[8 + i] = sel(l0, Q[11 - i], Q[7 - i]);
+#endif
 }
 
 // Magnitudes as the register-ring kernel's lanes consume them.  Lane l of a frame needs the 17

@@ -540,6 +540,19 @@ struct Stamps {
 };
 #endif
 
+// Where the per-lane constants come from: the LDS copy of the table (entry e of the lane at tabl[TE(e)]) or,
+// for a kernel that runs 2 waves per SIMD and has the registers, an array filled once per wave.
+struct TabLds {
+    const v2f* tabl;
+    __device__ __forceinline__ v2f get(int e) const { return lds_rd(&tabl[TE(e)]); }
+    __device__ __forceinline__ void pair(int e, v2f& a, v2f& b) const { lds_rd_pair(&tabl[TE(e)], a, b); }
+};
+struct TabReg {
+    const v2f* r;
+    __device__ __forceinline__ v2f get(int e) const { return r[e]; }
+    __device__ __forceinline__ void pair(int e, v2f& a, v2f& b) const { a = r[e]; b = r[e + 1]; }
+};
+
 // DFT-16 on the matrix cores.  The butterflies above cost 78 packed VALU operations per call and the fused
 // kernels are bound by VALU issue while the MFMA pipe idles, so the radix-16 pass is also available as a dense
 // real product C[32 x 64] = A[32 x 32] * B[32 x 64] on v_mfma_f32_32x32x2_f32 (exact fp32 fma chains of 16
@@ -555,15 +568,15 @@ struct Stamps {
 #define GL_MFMA16 0
 #endif
 typedef float f32x16_ __attribute__((ext_vector_type(16)));
-template <bool INV>
-__device__ __forceinline__ void dft16_mfma(v2f* z, const v2f* __restrict__ tabl) {
+template <bool INV, class TAB>
+__device__ __forceinline__ void dft16_mfma(v2f* z, const TAB& tb) {
     f32x16_ c0, c1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { c0[r] = 0.0f; c1[r] = 0.0f; }
 #pragma unroll
     for (int sp = 0; sp < 4; ++sp) {
         v2f a01, a23;
-        lds_rd_pair(&tabl[TE((INV ? kT2A16I : kT2A16F) + 2 * sp)], a01, a23);
+        tb.pair((INV ? kT2A16I : kT2A16F) + 2 * sp, a01, a23);
         const float av[4] = {a01.x, a01.y, a23.x, a23.y};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -587,29 +600,30 @@ __device__ __forceinline__ void dft16_mfma(v2f* z, const v2f* __restrict__ tabl)
         z[k2 + 2] = (v2f){c1[2 * q], c1[2 * q + 1]};
     }
 }
-template <bool INV>
-__device__ __forceinline__ void dft16_any(v2f* z, const v2f* __restrict__ tabl) {
-    if (GL_MFMA16) dft16_mfma<INV>(z, tabl);
+template <bool INV, class TAB>
+__device__ __forceinline__ void dft16_any(v2f* z, const TAB& tb) {
+    if (GL_MFMA16) dft16_mfma<INV>(z, tb);
     else dft16<INV>(z);
 }
 
 #ifndef GL_TW2_REG
 #define GL_TW2_REG 0   // 1: the seven W64 twiddles live in registers (callers pass them) instead of LDS reads
 #endif
+template <class TAB>
 __device__ __forceinline__ void fft_forward_1024(v2f* z, v2f* ex, int l, int a3, int g3, int kloB,
-                                                 const v2f* __restrict__ tabl, Stamps& st, const v2f* w2r = nullptr) {
+                                                 const TAB& tb, Stamps& st, const v2f* w2r = nullptr) {
     const int piL = a3 * kE1P + g3;                                    // pi(l)
     const int rhoL = (l & 15) * kE2Q + (l >> 4);                       // rho(l)
     const int rhoK = (kloB & 15) * kE2Q + (kloB >> 4);                 // rho(128 - l) (lane 0: rho(64))
-    dft16_any<false>(z, tabl);
+    dft16_any<false>(z, tb);
 #pragma unroll
     for (int pp = 0; pp < 7; ++pp) {
         v2f wa, wb;
-        lds_rd_pair(&tabl[TE(kT2Tw1 + 2 * pp)], wa, wb);
+        tb.pair(kT2Tw1 + 2 * pp, wa, wb);
         z[2 * pp + 1] = cmul(z[2 * pp + 1], wa);
         z[2 * pp + 2] = cmul(z[2 * pp + 2], wb);
     }
-    z[15] = cmul(z[15], lds_rd(&tabl[TE(kT2Tw1 + 14)]));
+    z[15] = cmul(z[15], tb.get(kT2Tw1 + 14));
     st.mark(1);
     if (!(GL_ABL & 1)) {
     prio_hi();
@@ -631,8 +645,8 @@ __device__ __forceinline__ void fft_forward_1024(v2f* z, v2f* ex, int l, int a3,
     for (int pp = 0; pp < 4; ++pp) {       // d = 2pp+1, 2pp+2
         v2f wa, wb;
         if (w2r) { wa = w2r[2 * pp]; wb = w2r[pp < 3 ? 2 * pp + 1 : 2 * pp]; }
-        else if (pp < 3) lds_rd_pair(&tabl[TE(kT2Tw2 + 2 * pp)], wa, wb);
-        else wa = wb = lds_rd(&tabl[TE(kT2Tw2 + 6)]);
+        else if (pp < 3) tb.pair(kT2Tw2 + 2 * pp, wa, wb);
+        else wa = wb = tb.get(kT2Tw2 + 6);
         z[2 * pp + 1] = cmul(z[2 * pp + 1], wa);
         z[8 + 2 * pp + 1] = cmul(z[8 + 2 * pp + 1], wa);
         if (pp < 3) {
@@ -660,8 +674,9 @@ __device__ __forceinline__ void fft_forward_1024(v2f* z, v2f* ex, int l, int a3,
     st.mark(5);
 }
 
+template <class TAB>
 __device__ __forceinline__ void fft_inverse_1024(v2f* z, v2f* ex, int l, int a3, int g3, int kloB,
-                                                 const v2f* __restrict__ tabl, Stamps& st, const v2f* w2r = nullptr) {
+                                                 const TAB& tb, Stamps& st, const v2f* w2r = nullptr) {
     const int piL = a3 * kE1P + g3;                                    // pi(l)
     const int rhoL = (l & 15) * kE2Q + (l >> 4);                       // rho(l)
     const int rhoK = (kloB & 15) * kE2Q + (kloB >> 4);                 // rho(128 - l) (lane 0: rho(64))
@@ -686,8 +701,8 @@ __device__ __forceinline__ void fft_inverse_1024(v2f* z, v2f* ex, int l, int a3,
     for (int pp = 0; pp < 4; ++pp) {       // d = 2pp+1, 2pp+2
         v2f wa, wb;
         if (w2r) { wa = w2r[2 * pp]; wb = w2r[pp < 3 ? 2 * pp + 1 : 2 * pp]; }
-        else if (pp < 3) lds_rd_pair(&tabl[TE(kT2Tw2 + 2 * pp)], wa, wb);
-        else wa = wb = lds_rd(&tabl[TE(kT2Tw2 + 6)]);
+        else if (pp < 3) tb.pair(kT2Tw2 + 2 * pp, wa, wb);
+        else wa = wb = tb.get(kT2Tw2 + 6);
         z[2 * pp + 1] = cmulc(z[2 * pp + 1], wa);
         z[8 + 2 * pp + 1] = cmulc(z[8 + 2 * pp + 1], wa);
         if (pp < 3) {
@@ -715,12 +730,12 @@ __device__ __forceinline__ void fft_inverse_1024(v2f* z, v2f* ex, int l, int a3,
 #pragma unroll
     for (int pp = 0; pp < 7; ++pp) {
         v2f wa, wb;
-        lds_rd_pair(&tabl[TE(kT2Tw1 + 2 * pp)], wa, wb);
+        tb.pair(kT2Tw1 + 2 * pp, wa, wb);
         z[2 * pp + 1] = cmulc(z[2 * pp + 1], wa);
         z[2 * pp + 2] = cmulc(z[2 * pp + 2], wb);
     }
-    z[15] = cmulc(z[15], lds_rd(&tabl[TE(kT2Tw1 + 14)]));
-    dft16_any<true>(z, tabl);
+    z[15] = cmulc(z[15], tb.get(kT2Tw1 + 14));
+    dft16_any<true>(z, tb);
     st.mark(11);
 }
 
@@ -750,8 +765,9 @@ __device__ __forceinline__ void lane0_chain(v2f& d0, v2f& d1, v2f& d2, v2f& d3, 
 // rfft split + magnitude projection + inverse split on the 9 lane-local mirror pairs.
 // lanes >= 1: P[c] = A[c], Q[c] = B[7-c]; lane 0 pairs inside its own two butterflies
 // (oracle/sim_fast2048.py); unit 8 is lane 0's self-mirrored bin 512 (a dummy elsewhere).
+template <class TAB>
 __device__ __forceinline__ void middle_project(v2f* z, bool l0, const float* m_lo, const float* m_hi,
-                                               const v2f* __restrict__ tabl) {
+                                               const TAB& tb) {
     v2f P[9], Q[9];
     const v2f z4 = z[4];
 #if GL_L0_MOV
@@ -782,7 +798,7 @@ __device__ __forceinline__ void middle_project(v2f* z, bool l0, const float* m_l
 #pragma unroll
     for (int pp = 0; pp < 4; ++pp) {
         v2f wa, wb;
-        lds_rd_pair(&tabl[TE(kT2Twp + 2 * pp)], wa, wb);
+        tb.pair(kT2Twp + 2 * pp, wa, wb);
         unit(2 * pp, wa);
         unit(2 * pp + 1, wb);
     }
@@ -854,10 +870,15 @@ struct AlignedArgs {
 #ifndef GL_MAG_PREFETCH
 #define GL_MAG_PREFETCH 2
 #endif
-// 12 waves in one workgroup per CU = 3 waves per SIMD (166 VGPRs fit the 168 budget); measured
-// 0.156 ms vs 0.167 ms per iteration for 2 workgroups of 4 (config 2)
+// 8 waves in one workgroup per CU = 2 waves per SIMD with up to 256 VGPRs each: the 47 per-lane constants of
+// the frame loop then live in registers (238 VGPRs, no spills) instead of being re-read from LDS at every
+// use, which removes a third of the LDS traffic and every table-read wait.  Measured on config 2:
+// 12 waves + LDS table 0.149 ms, 8 waves + LDS table 0.154 ms, 8 waves + register table 0.1435 ms.
+#ifndef GL_TAB_REG
+#define GL_TAB_REG 1
+#endif
 #ifndef GL_RR_WAVES
-#define GL_RR_WAVES 12
+#define GL_RR_WAVES 8
 #endif
 #ifndef GL_RR_OCC
 #define GL_RR_OCC 1
@@ -882,6 +903,15 @@ __global__ void __launch_bounds__(64 * kRRWaves, GL_RR_OCC) k_gl2048_regring(Ali
     const int run = grun - b * p.nruns;
     v2f* ex = smem + kT2Entries * 64 + wave * kRScratch;
     const v2f* tabl = smem + 2 * l;
+#if GL_TAB_REG
+    // 2 waves per SIMD leave 256 VGPRs per lane: the 47 constants the frame loop uses live in registers
+    v2f treg[kT2A16F];
+#pragma unroll
+    for (int e = 0; e < kT2A16F; ++e) treg[e] = lds_rd(&tabl[TE(e)]);
+    const TabReg tb{treg};
+#else
+    const TabLds tb{tabl};
+#endif
     const int T = p.T;
     const int f0 = run * p.G;
     const int f1 = min(f0 + p.G, T);
@@ -948,7 +978,7 @@ __global__ void __launch_bounds__(64 * kRRWaves, GL_RR_OCC) k_gl2048_regring(Ali
 #if GL_TW2_REG
     v2f w2reg[7];
 #pragma unroll
-    for (int d = 1; d < 8; ++d) w2reg[d - 1] = lds_rd(&tabl[TE(kT2Tw2 + d - 1)]);
+    for (int d = 1; d < 8; ++d) w2reg[d - 1] = tb.get(kT2Tw2 + d - 1);
     const v2f* w2r = w2reg;
 #else
     const v2f* w2r = nullptr;
@@ -989,10 +1019,10 @@ __global__ void __launch_bounds__(64 * kRRWaves, GL_RR_OCC) k_gl2048_regring(Ali
 
         v2f z[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) z[j] = xraw[j] * lds_rd(&tabl[TE(kT2Win + j)]);
+        for (int j = 0; j < 16; ++j) z[j] = xraw[j] * tb.get(kT2Win + j);
         st.mark(0);
-        fft_forward_1024(z, ex, l, a3, g3, kloB, tabl, st, w2r);
-        if (!(GL_ABL & 2)) middle_project(z, l0, m_lo, m_hi, tabl);
+        fft_forward_1024(z, ex, l, a3, g3, kloB, tb, st, w2r);
+        if (!(GL_ABL & 2)) middle_project(z, l0, m_lo, m_hi, tb);
         // the magnitude registers are free again: request the next frame's now, so the loads have
         // the inverse and the next forward transform to land (an HBM round trip under load is
         // longer than one transform) at no cost in registers
@@ -1000,10 +1030,10 @@ __global__ void __launch_bounds__(64 * kRRWaves, GL_RR_OCC) k_gl2048_regring(Ali
         load_mags(more ? n + 1 : n, m_lo, m_hi);
 #endif
         st.mark(6);
-        fft_inverse_1024(z, ex, l, a3, g3, kloB, tabl, st, w2r);
+        fft_inverse_1024(z, ex, l, a3, g3, kloB, tb, st, w2r);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            v2f w = lds_rd(&tabl[TE(kT2Win + j)]);      // 1/2048 is folded into the packed magnitudes
+            v2f w = tb.get(kT2Win + j);      // 1/2048 is folded into the packed magnitudes
             accr[j].x = fmaf(z[j].x, w.x, accr[j].x);
             accr[j].y = fmaf(z[j].y, w.y, accr[j].y);
         }
@@ -1184,9 +1214,9 @@ __global__ void __launch_bounds__(64 * kP1Waves, 1) k_gl1024_pair(Pair1024Args p
         const float kb = __any(b_nz) ? 1.0f : 0.0f;
 
         Stamps st;
-        fft_forward_1024(z, ex, l, a3, g3, kloB, tabl, st);
+        fft_forward_1024(z, ex, l, a3, g3, kloB, TabLds{tabl}, st);
         middle_two_frames(z, l0, ma, mb, ka, kb);
-        fft_inverse_1024(z, ex, l, a3, g3, kloB, tabl, st);
+        fft_inverse_1024(z, ex, l, a3, g3, kloB, TabLds{tabl}, st);
 
         // window, 1/1024, overlap-add: frame a then frame b (frame order, like the reference)
         {

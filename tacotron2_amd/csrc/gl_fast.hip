@@ -553,6 +553,18 @@ struct TabReg {
     __device__ __forceinline__ void pair(int e, v2f& a, v2f& b) const { a = r[e]; b = r[e + 1]; }
 };
 
+// the two FFT twiddle groups (entries kT2Tw1 .. kT2Twp-1) from registers, windows and split twiddles from LDS
+struct TabMixed {
+    const v2f* tabl;
+    const v2f* r;        // r[e - kT2Tw1]
+    __device__ __forceinline__ bool in_reg(int e) const { return e >= kT2Tw1 && e < kT2Twp; }
+    __device__ __forceinline__ v2f get(int e) const { return in_reg(e) ? r[e - kT2Tw1] : lds_rd(&tabl[TE(e)]); }
+    __device__ __forceinline__ void pair(int e, v2f& a, v2f& b) const {
+        if (in_reg(e)) { a = r[e - kT2Tw1]; b = r[e + 1 - kT2Tw1]; }
+        else lds_rd_pair(&tabl[TE(e)], a, b);
+    }
+};
+
 // DFT-16 on the matrix cores.  The butterflies above cost 78 packed VALU operations per call and the fused
 // kernels are bound by VALU issue while the MFMA pipe idles, so the radix-16 pass is also available as a dense
 // real product C[32 x 64] = A[32 x 32] * B[32 x 64] on v_mfma_f32_32x32x2_f32 (exact fp32 fma chains of 16
@@ -609,64 +621,121 @@ __device__ __forceinline__ void dft16_any(v2f* z, const TAB& tb) {
 #ifndef GL_TW2_REG
 #define GL_TW2_REG 0   // 1: the seven W64 twiddles live in registers (callers pass them) instead of LDS reads
 #endif
-template <class TAB>
-__device__ __forceinline__ void fft_forward_1024(v2f* z, v2f* ex, int l, int a3, int g3, int kloB,
-                                                 const TAB& tb, Stamps& st, const v2f* w2r = nullptr) {
-    const int piL = a3 * kE1P + g3;                                    // pi(l)
-    const int rhoL = (l & 15) * kE2Q + (l >> 4);                       // rho(l)
-    const int rhoK = (kloB & 15) * kE2Q + (kloB >> 4);                 // rho(128 - l) (lane 0: rho(64))
-    dft16_any<false>(z, tb);
+// ---- the 1024-point transform in phases -----------------------------------------------------------------
+// (the composite fft_forward_1024 / fft_inverse_1024 below run them back to back; the software-pipelined
+// register-ring loop interleaves the phases of two frames so that one frame's arithmetic covers the other's
+// LDS round trips)
+struct LanePos {
+    int a3, g3, piL, rhoL, rhoK;
+    __device__ __forceinline__ LanePos(int l, int kloB)
+        : a3(l & 7), g3(l >> 3), piL((l & 7) * kE1P + (l >> 3)), rhoL((l & 15) * kE2Q + (l >> 4)),
+          rhoK((kloB & 15) * kE2Q + (kloB >> 4)) {}
+};
+template <bool INV, class TAB>
+__device__ __forceinline__ void twiddle1(v2f* z, const TAB& tb) {        // z[k2] *= W1024^(+-l*k2)
 #pragma unroll
     for (int pp = 0; pp < 7; ++pp) {
         v2f wa, wb;
         tb.pair(kT2Tw1 + 2 * pp, wa, wb);
-        z[2 * pp + 1] = cmul(z[2 * pp + 1], wa);
-        z[2 * pp + 2] = cmul(z[2 * pp + 2], wb);
+        z[2 * pp + 1] = ctw<INV>(z[2 * pp + 1], wa);
+        z[2 * pp + 2] = ctw<INV>(z[2 * pp + 2], wb);
     }
-    z[15] = cmul(z[15], tb.get(kT2Tw1 + 14));
-    st.mark(1);
-    if (!(GL_ABL & 1)) {
-    prio_hi();
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int k2 = 0; k2 < 16; ++k2) ex[k2 * kE1S + piL] = z[k2];
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int bb = 0; bb < 8; bb += 2)
-            lds_rd_pair(&ex[(g3 + 8 * h) * kE1S + a3 * kE1P + bb], z[8 * h + bb], z[8 * h + bb + 1]);
-    prio_lo();
-    }
-    st.mark(2);
-    dft8<false>(z);
-    dft8<false>(z + 8);
+    z[15] = ctw<INV>(z[15], tb.get(kT2Tw1 + 14));
+}
+template <bool INV, class TAB>
+__device__ __forceinline__ void twiddle2(v2f* z, const TAB& tb, const v2f* w2r) {   // z[d], z[8+d] *= W64^(+-a*d)
 #pragma unroll
     for (int pp = 0; pp < 4; ++pp) {       // d = 2pp+1, 2pp+2
         v2f wa, wb;
         if (w2r) { wa = w2r[2 * pp]; wb = w2r[pp < 3 ? 2 * pp + 1 : 2 * pp]; }
         else if (pp < 3) tb.pair(kT2Tw2 + 2 * pp, wa, wb);
         else wa = wb = tb.get(kT2Tw2 + 6);
-        z[2 * pp + 1] = cmul(z[2 * pp + 1], wa);
-        z[8 + 2 * pp + 1] = cmul(z[8 + 2 * pp + 1], wa);
+        z[2 * pp + 1] = ctw<INV>(z[2 * pp + 1], wa);
+        z[8 + 2 * pp + 1] = ctw<INV>(z[8 + 2 * pp + 1], wa);
         if (pp < 3) {
-            z[2 * pp + 2] = cmul(z[2 * pp + 2], wb);
-            z[8 + 2 * pp + 2] = cmul(z[8 + 2 * pp + 2], wb);
+            z[2 * pp + 2] = ctw<INV>(z[2 * pp + 2], wb);
+            z[8 + 2 * pp + 2] = ctw<INV>(z[8 + 2 * pp + 2], wb);
         }
     }
-    st.mark(3);
-    if (!(GL_ABL & 1)) {
-    prio_hi();
+}
+// exchange 1: register k2 <-> lane bits g3.  "cols" side: 16 x b64 at pi(l); "rows" side: 2 x 4 x b128
+__device__ __forceinline__ void ex1_put_cols(const v2f* z, v2f* ex, const LanePos& lp) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) ex[k2 * kE1S + lp.piL] = z[k2];
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void ex1_get_rows(v2f* z, const v2f* ex, const LanePos& lp) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int bb = 0; bb < 8; bb += 2)
+            lds_rd_pair(&ex[(lp.g3 + 8 * h) * kE1S + lp.a3 * kE1P + bb], z[8 * h + bb], z[8 * h + bb + 1]);
+}
+__device__ __forceinline__ void ex1_put_rows(const v2f* z, v2f* ex, const LanePos& lp) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int bb = 0; bb < 8; bb += 2)
+            lds_wr_pair(&ex[(lp.g3 + 8 * h) * kE1S + lp.a3 * kE1P + bb], z[8 * h + bb], z[8 * h + bb + 1]);
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void ex1_get_cols(v2f* z, const v2f* ex, const LanePos& lp) {
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) z[k2] = lds_rd(&ex[k2 * kE1S + lp.piL]);
+}
+// exchange 2: register d <-> lane bits a3.  "rows" side: 2 x 4 x b128; "cols" side: 16 x b64 at rho(l), rho(128-l)
+__device__ __forceinline__ void ex2_put_rows(const v2f* z, v2f* ex, const LanePos& lp) {
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int d = 0; d < 8; d += 2)
-            lds_wr_pair(&ex[a3 * kE2S + (g3 + 8 * h) * kE2Q + d], z[8 * h + d], z[8 * h + d + 1]);
+            lds_wr_pair(&ex[lp.a3 * kE2S + (lp.g3 + 8 * h) * kE2Q + d], z[8 * h + d], z[8 * h + d + 1]);
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void ex2_get_cols(v2f* z, const v2f* ex, const LanePos& lp) {
+#pragma unroll
+    for (int a = 0; a < 8; ++a) { z[a] = lds_rd(&ex[a * kE2S + lp.rhoL]); z[8 + a] = lds_rd(&ex[a * kE2S + lp.rhoK]); }
+}
+__device__ __forceinline__ void ex2_put_cols(const v2f* z, v2f* ex, const LanePos& lp) {
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int a = 0; a < 8; ++a) { z[a] = lds_rd(&ex[a * kE2S + rhoL]); z[8 + a] = lds_rd(&ex[a * kE2S + rhoK]); }
-    prio_lo();
+    for (int a = 0; a < 8; ++a) { ex[a * kE2S + lp.rhoL] = z[a]; ex[a * kE2S + lp.rhoK] = z[8 + a]; }
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void ex2_get_rows(v2f* z, const v2f* ex, const LanePos& lp) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int d = 0; d < 8; d += 2)
+            lds_rd_pair(&ex[lp.a3 * kE2S + (lp.g3 + 8 * h) * kE2Q + d], z[8 * h + d], z[8 * h + d + 1]);
+}
+
+template <class TAB>
+__device__ __forceinline__ void fft_forward_1024(v2f* z, v2f* ex, int l, int a3, int g3, int kloB,
+                                                 const TAB& tb, Stamps& st, const v2f* w2r = nullptr) {
+    const LanePos lp(l, kloB);
+    dft16_any<false>(z, tb);
+    twiddle1<false>(z, tb);
+    st.mark(1);
+    if (!(GL_ABL & 1)) {
+        prio_hi();
+        ex1_put_cols(z, ex, lp);
+        ex1_get_rows(z, ex, lp);
+        prio_lo();
+    }
+    st.mark(2);
+    dft8<false>(z);
+    dft8<false>(z + 8);
+    twiddle2<false>(z, tb, w2r);
+    st.mark(3);
+    if (!(GL_ABL & 1)) {
+        prio_hi();
+        ex2_put_rows(z, ex, lp);
+        ex2_get_cols(z, ex, lp);
+        prio_lo();
     }
     st.mark(4);
     dft8<false>(z);
@@ -677,64 +746,29 @@ __device__ __forceinline__ void fft_forward_1024(v2f* z, v2f* ex, int l, int a3,
 template <class TAB>
 __device__ __forceinline__ void fft_inverse_1024(v2f* z, v2f* ex, int l, int a3, int g3, int kloB,
                                                  const TAB& tb, Stamps& st, const v2f* w2r = nullptr) {
-    const int piL = a3 * kE1P + g3;                                    // pi(l)
-    const int rhoL = (l & 15) * kE2Q + (l >> 4);                       // rho(l)
-    const int rhoK = (kloB & 15) * kE2Q + (kloB >> 4);                 // rho(128 - l) (lane 0: rho(64))
+    const LanePos lp(l, kloB);
     dft8<true>(z);
     dft8<true>(z + 8);
     st.mark(7);
     if (!(GL_ABL & 1)) {
-    prio_hi();
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int a = 0; a < 8; ++a) { ex[a * kE2S + rhoL] = z[a]; ex[a * kE2S + rhoK] = z[8 + a]; }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int d = 0; d < 8; d += 2)
-            lds_rd_pair(&ex[a3 * kE2S + (g3 + 8 * h) * kE2Q + d], z[8 * h + d], z[8 * h + d + 1]);
-    prio_lo();
+        prio_hi();
+        ex2_put_cols(z, ex, lp);
+        ex2_get_rows(z, ex, lp);
+        prio_lo();
     }
     st.mark(8);
-#pragma unroll
-    for (int pp = 0; pp < 4; ++pp) {       // d = 2pp+1, 2pp+2
-        v2f wa, wb;
-        if (w2r) { wa = w2r[2 * pp]; wb = w2r[pp < 3 ? 2 * pp + 1 : 2 * pp]; }
-        else if (pp < 3) tb.pair(kT2Tw2 + 2 * pp, wa, wb);
-        else wa = wb = tb.get(kT2Tw2 + 6);
-        z[2 * pp + 1] = cmulc(z[2 * pp + 1], wa);
-        z[8 + 2 * pp + 1] = cmulc(z[8 + 2 * pp + 1], wa);
-        if (pp < 3) {
-            z[2 * pp + 2] = cmulc(z[2 * pp + 2], wb);
-            z[8 + 2 * pp + 2] = cmulc(z[8 + 2 * pp + 2], wb);
-        }
-    }
+    twiddle2<true>(z, tb, w2r);
     dft8<true>(z);
     dft8<true>(z + 8);
     st.mark(9);
     if (!(GL_ABL & 1)) {
-    prio_hi();
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int bb = 0; bb < 8; bb += 2)
-            lds_wr_pair(&ex[(g3 + 8 * h) * kE1S + a3 * kE1P + bb], z[8 * h + bb], z[8 * h + bb + 1]);
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int k2 = 0; k2 < 16; ++k2) z[k2] = lds_rd(&ex[k2 * kE1S + piL]);
-    prio_lo();
+        prio_hi();
+        ex1_put_rows(z, ex, lp);
+        ex1_get_cols(z, ex, lp);
+        prio_lo();
     }
     st.mark(10);
-#pragma unroll
-    for (int pp = 0; pp < 7; ++pp) {
-        v2f wa, wb;
-        tb.pair(kT2Tw1 + 2 * pp, wa, wb);
-        z[2 * pp + 1] = cmulc(z[2 * pp + 1], wa);
-        z[2 * pp + 2] = cmulc(z[2 * pp + 2], wb);
-    }
-    z[15] = cmulc(z[15], tb.get(kT2Tw1 + 14));
+    twiddle1<true>(z, tb);
     dft16_any<true>(z, tb);
     st.mark(11);
 }
@@ -874,8 +908,15 @@ struct AlignedArgs {
 // the frame loop then live in registers (238 VGPRs, no spills) instead of being re-read from LDS at every
 // use, which removes a third of the LDS traffic and every table-read wait.  Measured on config 2:
 // 12 waves + LDS table 0.149 ms, 8 waves + LDS table 0.154 ms, 8 waves + register table 0.1435 ms.
+// GL_TAB_REG: 0 = constants read from LDS at every use, 1 = all 47 in registers, 2 = the FFT twiddles (22) in
+// registers, windows and split twiddles from LDS -- what fits beside the second frame of the pipelined loop.
+// GL_PIPE: 1 = software-pipelined loop over two frames (below).  Measured on config 2, 8 waves per CU:
+// LDS table 0.154 ms; register table 0.1460; pipelined + LDS table 0.151; pipelined + twiddles in registers 0.1420.
 #ifndef GL_TAB_REG
-#define GL_TAB_REG 1
+#define GL_TAB_REG 2
+#endif
+#ifndef GL_PIPE
+#define GL_PIPE 1
 #endif
 #ifndef GL_RR_WAVES
 #define GL_RR_WAVES 8
@@ -903,12 +944,17 @@ __global__ void __launch_bounds__(64 * kRRWaves, GL_RR_OCC) k_gl2048_regring(Ali
     const int run = grun - b * p.nruns;
     v2f* ex = smem + kT2Entries * 64 + wave * kRScratch;
     const v2f* tabl = smem + 2 * l;
-#if GL_TAB_REG
+#if GL_TAB_REG == 1
     // 2 waves per SIMD leave 256 VGPRs per lane: the 47 constants the frame loop uses live in registers
     v2f treg[kT2A16F];
 #pragma unroll
     for (int e = 0; e < kT2A16F; ++e) treg[e] = lds_rd(&tabl[TE(e)]);
     const TabReg tb{treg};
+#elif GL_TAB_REG == 2
+    v2f treg[kT2Twp - kT2Tw1];
+#pragma unroll
+    for (int e = kT2Tw1; e < kT2Twp; ++e) treg[e - kT2Tw1] = lds_rd(&tabl[TE(e)]);
+    const TabMixed tb{tabl, treg};
 #else
     const TabLds tb{tabl};
 #endif
@@ -992,6 +1038,100 @@ __global__ void __launch_bounds__(64 * kRRWaves, GL_RR_OCC) k_gl2048_regring(Ali
     Stamps st;
     st.start();
 
+#if GL_PIPE
+    // Software pipeline over two frames.  Frames of one iteration are independent (every frame reads x_in
+    // and adds into x_out), so the forward transform of frame n+1 ("A") is interleaved with the projection
+    // and inverse transform of frame n ("B"): each of the four LDS transposes is issued and then followed
+    // by arithmetic of the OTHER frame, so its round trip is covered by work of the same wave instead of
+    // depending on what the one other wave of the SIMD happens to be doing.  Both frames use the same
+    // scratch: LDS operations of a wave execute in program order, and the order below alternates
+    // A.ex1, B.ex2, A.ex2, B.ex1, each written and read completely before the next is written.
+    const LanePos lp(l, kloB);
+    auto window_in = [&](v2f* z) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) z[j] = xraw[j] * tb.get(kT2Win + j);
+    };
+    auto rows_request = [&](int frame, bool live, v2f* xn, v2f* xt) {      // the HS rows frame `frame` adds
+#pragma unroll
+        for (int jj = 0; jj < HS; ++jj) {
+            const int rel = (frame - 1 - f0) * H + kN + 128 * jj;
+            const float* xp = live ? xrun + rel : zrow;
+            const float* tp = live ? tail_ptr(rel) : zrow;
+            xn[jj] = *reinterpret_cast<const v2f*>(xp);
+            xt[jj] = *reinterpret_cast<const v2f*>(tp);
+        }
+    };
+    auto ring_advance = [&](const v2f* xn, const v2f* xt) {
+#pragma unroll
+        for (int j = 0; j < OVR; ++j) xraw[j] = xraw[j + HS];
+#pragma unroll
+        for (int jj = 0; jj < HS; ++jj) xraw[OVR + jj] = xn[jj] + xt[jj];
+    };
+    auto emit = [&](v2f* z, int n) {                 // window, overlap-add, store the HS finished rows
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            v2f w = tb.get(kT2Win + j);              // 1/2048 is folded into the packed magnitudes
+            accr[j].x = fmaf(z[j].x, w.x, accr[j].x);
+            accr[j].y = fmaf(z[j].y, w.y, accr[j].y);
+        }
+        float* orow = p.x_out + (long long)b * p.L + (long long)n * H + 2 * l;
+#pragma unroll
+        for (int jj = 0; jj < HS; ++jj) *reinterpret_cast<v2f*>(orow + 128 * jj) = accr[jj];
+#pragma unroll
+        for (int j = 0; j < OVR; ++j) accr[j] = accr[j + HS];
+#pragma unroll
+        for (int jj = 0; jj < HS; ++jj) accr[OVR + jj] = (v2f){0.0f, 0.0f};
+    };
+
+    // prologue: forward transform of the run's first frame
+    v2f zf[16];
+    {
+        v2f xn[HS], xt[HS];
+        rows_request(f0 + 1, f0 + 1 < f1, xn, xt);
+        window_in(zf);
+        fft_forward_1024(zf, ex, l, a3, g3, kloB, tb, st, w2r);
+        ring_advance(xn, xt);                        // xraw = input of frame f0+1
+    }
+    for (int n = f0; n + 1 < f1; ++n) {
+        v2f xn[HS], xt[HS];
+        rows_request(n + 2, n + 2 < f1, xn, xt);
+        v2f zA[16];
+        window_in(zA);                               // A: frame n+1
+        dft16_any<false>(zA, tb);
+        twiddle1<false>(zA, tb);
+        ex1_put_cols(zA, ex, lp);
+        ex1_get_rows(zA, ex, lp);
+        middle_project(zf, l0, m_lo, m_hi, tb);      // B: frame n
+        load_mags(n + 1, m_lo, m_hi);
+        dft8<true>(zf);
+        dft8<true>(zf + 8);
+        ex2_put_cols(zf, ex, lp);
+        ex2_get_rows(zf, ex, lp);
+        dft8<false>(zA);                             // A
+        dft8<false>(zA + 8);
+        twiddle2<false>(zA, tb, w2r);
+        ex2_put_rows(zA, ex, lp);
+        ex2_get_cols(zA, ex, lp);
+        twiddle2<true>(zf, tb, w2r);                 // B
+        dft8<true>(zf);
+        dft8<true>(zf + 8);
+        ex1_put_rows(zf, ex, lp);
+        ex1_get_cols(zf, ex, lp);
+        dft8<false>(zA);                             // A: spectrum of frame n+1 complete
+        dft8<false>(zA + 8);
+        twiddle1<true>(zf, tb);                      // B
+        dft16_any<true>(zf, tb);
+        emit(zf, n);
+        ring_advance(xn, xt);                        // xraw = input of frame n+2
+#pragma unroll
+        for (int j = 0; j < 16; ++j) zf[j] = zA[j];
+    }
+    {   // epilogue: the run's last frame has no successor to overlap with
+        middle_project(zf, l0, m_lo, m_hi, tb);
+        fft_inverse_1024(zf, ex, l, a3, g3, kloB, tb, st, w2r);
+        emit(zf, f1 - 1);
+    }
+#else
     for (int n = f0; n < f1; ++n) {
         const long long sn = (long long)n * H;
 
@@ -1051,6 +1191,8 @@ __global__ void __launch_bounds__(64 * kRRWaves, GL_RR_OCC) k_gl2048_regring(Ali
 #endif
         st.mark(12);
     }
+
+#endif
 
     // partial sums of the N-H samples after the run's last frame
     const long long se = (long long)f1 * H;

@@ -1403,6 +1403,165 @@ __global__ void __launch_bounds__(64 * kP1Waves, 1) k_gl1024_pair(Pair1024Args p
     }
 }
 
+// Second version of the n_fft-1024 kernel: 8 waves per CU instead of 4.  The x ring is gone (a frame's samples
+// come straight from global memory: consecutive frames overlap, so they hit L1/L2), the FFT twiddles live in
+// registers and only the 16 window entries are copied to LDS, and 1/1024 is folded into the magnitudes so the
+// inverse window is the forward window: 8 KB + 8 x (10.4 KB scratch + 8 KB accumulator ring) = 155 KB.
+// Runs of all utterances are numbered consecutively, like the register-ring kernel's.
+constexpr int kP2Waves = 8;
+constexpr int kP2WaveLds = kRScratch + kP1Ring / 2;      // v2f units: transpose scratch + one float ring
+struct Pair2Args {
+    Pair1024Args a;
+    int B;
+};
+__global__ void __launch_bounds__(64 * kP2Waves, 1) k_gl1024_pair2(Pair2Args pp) {
+    const Pair1024Args& p = pp.a;
+    __shared__ __attribute__((aligned(16))) v2f smem[16 * 64 + kP2Waves * kP2WaveLds];
+    const int l = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grun = blockIdx.x * kP2Waves + wave;
+    for (int i = threadIdx.x; i < 16 * 64; i += 64 * kP2Waves) smem[i] = p.tab[i];      // window entries 0..15
+    __syncthreads();
+    if (grun >= pp.B * p.nruns) return;          // wave-uniform; no barrier after this point
+    const int b = grun / p.nruns;
+    const int run = grun - b * p.nruns;
+    v2f* ex = smem + 16 * 64 + wave * kP2WaveLds;
+    float* acc = reinterpret_cast<float*>(ex + kRScratch);
+    const v2f* tabl = smem + 2 * l;
+    v2f treg[kT2Twp - kT2Tw1];
+    {
+        const v2f* tg = p.tab + 2 * l;
+#pragma unroll
+        for (int e = kT2Tw1; e < kT2Twp; ++e) treg[e - kT2Tw1] = tg[TE(e)];
+    }
+    const TabMixed tb{tabl, treg};
+
+    const int H = p.H, T = p.T;
+    const int f0 = run * p.G;
+    const int f1 = min(f0 + p.G, T);
+    const int ovl = kN1 - H;
+    const int a3 = l & 7, g3 = l >> 3;
+    const int kloB = l ? 128 - l : 64;
+    const bool l0 = (l == 0);
+    const float* xr = p.x_in + (long long)b * p.L;
+    // tails (partial sums the producer of x_in left aside): the previous run's cover the first N-H samples of
+    // this run's region, this run's own the first N-H samples of the next run's region
+    const bool has_tail = (p.tail_in != nullptr);
+    const float* t_prev = (has_tail && run >= 1) ? p.tail_in + ((long long)b * p.nruns + run - 1) * ovl : nullptr;
+    const float* t_own = (has_tail && run + 1 < p.nruns) ? p.tail_in + ((long long)b * p.nruns + run) * ovl : nullptr;
+    const long long s_lo = (long long)f0 * H;                 // first sample of this run's region
+    const long long s_hi = (long long)(f0 + p.G) * H;         // first sample of the next run's region
+    auto sample = [&](long long s, bool tails) -> float {
+        float v = xr[s];
+        if (tails) {
+            const long long dp = s - s_lo, dn = s - s_hi;
+            if (t_prev != nullptr && dp < ovl) v += t_prev[dp];
+            if (t_own != nullptr && dn >= 0 && dn < ovl) v += t_own[dn];
+        }
+        return v;
+    };
+
+#pragma unroll
+    for (int i = 0; i < kP1Ring / 64; ++i) acc[l + 64 * i] = 0.0f;
+
+    int kk[9];                                   // magnitude index of the lane's 9 units: min(k, 1024-k)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        int k = l ? (l + 128 * u) : (u < 4 ? 128 * u : 64 + 128 * (u - 4));
+        kk[u] = k <= 512 ? k : 1024 - k;
+    }
+    kk[8] = 512;
+
+    for (int n = f0; n < f1; n += 2) {
+        const bool two = (n + 1 < f1);
+        const long long sn = (long long)n * H;
+        // wave-uniform: does this pair read any sample that has a tail?
+        const bool tails = has_tail && ((t_prev != nullptr && sn < s_lo + ovl) || (t_own != nullptr && sn + kN1 + H > s_hi));
+
+        float ma[9], mb[9];
+        {
+            const float* ra = p.mag + ((long long)b * T + n) * (kN1 / 2 + 1);
+            const float* rb = ra + (two ? (kN1 / 2 + 1) : 0);
+#pragma unroll
+            for (int u = 0; u < 9; ++u) {
+                ma[u] = ra[kk[u]] * (1.0f / kM);                      // 1/M of the inverse transform (exact)
+                mb[u] = two ? rb[kk[u]] * (1.0f / kM) : 0.0f;
+            }
+        }
+        v2f z[16];
+        bool a_nz = false, b_nz = false;
+        if (tails) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                z[j].x = sample(sn + l + 64 * j, true);
+                z[j].y = two ? sample(sn + H + l + 64 * j, true) : 0.0f;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                z[j].x = xr[sn + l + 64 * j];
+                z[j].y = two ? xr[sn + H + l + 64 * j] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            a_nz |= (z[j].x != 0.0f);
+            b_nz |= (z[j].y != 0.0f);
+            z[j] = z[j] * tb.get(kT2Win + j);
+        }
+        // an all-zero input frame must give an exactly zero spectrum (phase 0 after projection,
+        // audio_utilities.py:181): its partner's rounding noise must not set its phase
+        const float ka = __any(a_nz) ? 1.0f : 0.0f;
+        const float kb = __any(b_nz) ? 1.0f : 0.0f;
+
+        Stamps st;
+        fft_forward_1024(z, ex, l, a3, g3, kloB, tb, st);
+        middle_two_frames(z, l0, ma, mb, ka, kb);
+        fft_inverse_1024(z, ex, l, a3, g3, kloB, tb, st);
+
+        // window, overlap-add: frame a then frame b (frame order, like the reference)
+        {
+            const int base_a = (int)(sn & (kP1Ring - 1));
+            const int base_b = (int)((sn + H) & (kP1Ring - 1));
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                v2f w = tb.get(kT2Win + j);
+                acc[(base_a + l + 64 * j) & (kP1Ring - 1)] += z[j].x * w.x;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (two) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    v2f w = tb.get(kT2Win + j);
+                    acc[(base_b + l + 64 * j) & (kP1Ring - 1)] += z[j].y * w.y;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // samples [sn, sn + H) (or 2H) are complete: emit once and clear
+            const int done = two ? 2 * H : H;
+            float* orow = p.x_out + (long long)b * p.L;
+            for (int i = l; i < done; i += 64) {
+                int q = (int)((sn + i) & (kP1Ring - 1));
+                orow[sn + i] = acc[q];
+                acc[q] = 0.0f;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+
+    // partial sums of the N-H samples after the run's last frame
+    const long long se = (long long)f1 * H;
+    if (f1 == T) {
+        float* orow = p.x_out + (long long)b * p.L;
+        for (int i = l; i < ovl; i += 64) orow[se + i] = acc[(int)((se + i) & (kP1Ring - 1))];
+        for (int i = l; i < H; i += 64) orow[se + ovl + i] = 0.0f;
+    } else {
+        float* trow = p.tail_out + ((long long)b * p.nruns + run) * ovl;
+        for (int i = l; i < ovl; i += 64) trow[i] = acc[(int)((se + i) & (kP1Ring - 1))];
+    }
+}
+
 // x_out[s] = x_main[s] + tail of the previous run (final fold after the last iteration)
 __global__ void __launch_bounds__(256) k_fold_tails(const float* __restrict__ x_main, const float* __restrict__ tail,
                                                     float* __restrict__ x_out, long long L, int g_h, int nruns,
@@ -1676,9 +1835,17 @@ int run_pair1024(gl_plan* p, const float* mag, const float* x0, float* x_out, in
     int rc = ensure_table2(p);
     if (!rc) rc = ensure_buffers(p);
     if (rc) return rc;
-    const int G = pick_run_length(p, B, T, kP1Waves);
+    // small problems (config 1: one utterance) cannot fill 8 waves per CU and run faster on the first version,
+    // whose LDS x ring hides the load latency a lone wave sees (measured 1.47 vs 1.70 ms for B=1, T=641);
+    // from a few frames per wave slot on, the second version wins (config 5: 5.86 vs 8.37 ms)
+    static const char* force = getenv("GL_P1_VERSION");        // experiments: "1" or "2"
+    const bool v1 = force ? (force[0] == '1') : ((long long)B * T < 24LL * p->n_cu);
+    const int waves = v1 ? kP1Waves : kP2Waves;
+    const int G = pick_run_length(p, B, T, waves);
     const int nruns = (T + G - 1) / G;
-    Pair1024Args a = {};
+    Pair2Args aa = {};
+    Pair1024Args& a = aa.a;
+    aa.B = B;
     a.mag = mag;
     a.tab = reinterpret_cast<const v2f*>(p->d_fast_tab2);
     a.H = p->hop;
@@ -1686,7 +1853,6 @@ int run_pair1024(gl_plan* p, const float* mag, const float* x0, float* x_out, in
     a.G = G;
     a.nruns = nruns;
     a.L = gl_len(p->n_fft, p->hop, T);
-    dim3 grid((nruns + kP1Waves - 1) / kP1Waves, B);
     const float* src = x0;
     const float* src_tail = nullptr;
     const bool post = gl_post_needed(p);
@@ -1699,7 +1865,11 @@ int run_pair1024(gl_plan* p, const float* mag, const float* x0, float* x_out, in
         a.tail_in = src_tail;
         a.x_out = dst;
         a.tail_out = dst_tail;
-        hipLaunchKernelGGL(k_gl1024_pair, grid, dim3(64 * kP1Waves), 0, st, a);
+        if (v1)
+            hipLaunchKernelGGL(k_gl1024_pair, dim3((nruns + kP1Waves - 1) / kP1Waves, B), dim3(64 * kP1Waves), 0, st, a);
+        else
+            hipLaunchKernelGGL(k_gl1024_pair2, dim3((unsigned)(((long long)nruns * B + kP2Waves - 1) / kP2Waves)),
+                               dim3(64 * kP2Waves), 0, st, aa);
         GL_HIP_CHECK(hipGetLastError());
         src = dst;
         src_tail = (nruns > 1) ? dst_tail : nullptr;

@@ -582,3 +582,18 @@ def test_ragged_batch_equals_per_utterance_runs(N, H, path):
                                                   x_init=torch.from_numpy(x0[b, :Lb]), device="cuda:0").cpu().numpy()
         assert np.max(np.abs(x[b, :Lb] - alone)) <= 2e-5 * np.max(np.abs(alone))
     get_plan(N, H, T, len(lens), "cuda:0").set_path(0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("version", ["1", "2"])
+def test_n1024_both_kernel_versions_on_small_cases(version):
+    """gl_run picks the n_fft-1024 kernel version by problem size; force each one (GL_P1_VERSION is read once
+    per process, hence the subprocess) over small cases with tails, odd frame counts and a zero frame."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, GL_P1_VERSION=version)
+    r = subprocess.run([sys.executable, os.path.join(here, "p1_version_check.py")], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

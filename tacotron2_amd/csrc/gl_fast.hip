@@ -1,13 +1,20 @@
-// Fused wave-per-frame Griffin-Lim kernels for gfx950 (MI355X), n_fft = 2048.
+// Fused wave-per-frame Griffin-Lim kernels for gfx950 (MI355X), n_fft = 2048 and 1024.
 //
 // One 64-lane wavefront owns a run of G consecutive frames of one utterance and
 // keeps the whole per-frame pipeline on chip:
 //
-//   x ring (LDS) -> window -> 1024-point complex FFT in registers (16 points per
+//   x ring -> window -> 1024-point complex FFT in registers (16 points per
 //   lane: radix-16, radix-8, radix-8 with two LDS transposes) -> real-FFT
 //   post-process + magnitude projection + inverse pre-process, lane-local ->
-//   inverse FFT (mirror image) -> window -> overlap-add into an LDS ring ->
+//   inverse FFT (mirror image) -> window -> overlap-add ring ->
 //   each output sample written to HBM exactly once.
+//
+// Kernels, in the order of the file:
+//   k_fast2048<MODE>     n_fft 2048, any hop; rings in LDS; also the single-shot STFT / ISTFT
+//   k_gl2048_regring<HS> n_fft 2048, hop 128*HS: rings in registers, two frames in flight per wave
+//                        (the benchmark kernel)
+//   k_gl1024_pair / k_gl1024_pair2   n_fft 1024, any hop: two real frames per complex FFT
+// The FFT core (dft16/dft8, twiddle1/2, ex1_*/ex2_* transposes, middle_project) is shared.
 //
 // The index decomposition n = a + 8b + 64 n2, k = k2 + 16 d + 128 c and the lane
 // assignment of the last pass (lane l owns the radix-8 butterflies k_lo = l and
@@ -460,9 +467,10 @@ __global__ void __launch_bounds__(64) k_fast2048(FastArgs p) {
 // samples is a shift by HS registers: the un-windowed input frame (xraw) and the
 // overlap-add accumulator (accr) both live in registers and slide by HS rows per
 // frame.  Per frame the wave loads HS new rows (prefetched one frame ahead), stores
-// HS finished rows, and uses LDS only for the four FFT transposes (9 KB per wave).
-// Window and twiddles are re-read from a 32 KB L1/L2-resident table at their use
-// sites to keep the register budget at 3 waves per SIMD.
+// HS finished rows, and uses LDS for the four FFT transposes (10.4 KB per wave) and the
+// window / split-twiddle constants (33 KB table shared by the workgroup); the FFT twiddles
+// live in registers.  8 waves per CU (2 per SIMD, 242 VGPRs); the frame loop keeps two
+// frames in flight per wave (GL_PIPE, see the loop).
 // =====================================================================================
 #ifndef GL_ABL
 #define GL_ABL 0   // timing experiments only: 1 skip LDS transposes, 2 skip projection step, 4 constant twiddles
@@ -928,7 +936,7 @@ constexpr int kRRWaves = GL_RR_WAVES;        // waves per workgroup; they only s
 
 template <int HS>
 __global__ void __launch_bounds__(64 * kRRWaves, GL_RR_OCC) k_gl2048_regring(AlignedArgs p) {
-    // one LDS array (table + per-wave transpose scratch): 32 KB + 12 x 9 KB = 140 KB -> 1 WG / CU
+    // one LDS array (table + per-wave transpose scratch): 33 KB + 8 x 10.4 KB = 116 KB -> 1 WG / CU
     __shared__ __attribute__((aligned(16))) v2f smem[kT2Entries * 64 + kRRWaves * kRScratch];
     constexpr int H = 128 * HS;
     constexpr int OVR = 16 - HS;                 // rows shared with the next frame / next run
@@ -1279,7 +1287,7 @@ __device__ __forceinline__ void middle_two_frames(v2f* z, bool l0, const float* 
 }
 
 __global__ void __launch_bounds__(64 * kP1Waves, 1) k_gl1024_pair(Pair1024Args p) {
-    // table 32 KB + 4 x (9 KB transpose scratch + 8 KB x ring + 8 KB accumulator ring) = 132 KB
+    // table 41 KB + 4 x (10.4 KB transpose scratch + 8 KB x ring + 8 KB accumulator ring) = 147 KB
     __shared__ __attribute__((aligned(16))) v2f smem[kT2EntriesPair * 64 + kP1Waves * kP1WaveLds];
     const int l = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

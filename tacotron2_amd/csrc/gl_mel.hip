@@ -20,6 +20,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kTileT = 32;      // rows (t) per wave
 constexpr int kTileF = 128;     // cols (f) per wave: 4 accumulators of 32
 constexpr int kWaves = 4;       // waves per workgroup, stacked along t
+constexpr int kKC = 80;         // mel bands per LDS stage of the filterbank tile (40 KB)
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 // LOGMEL = false: mel is [B][K][T] linear amplitude (what save_mel_to_wav receives).
 // LOGMEL = true : mel is [B][T][K] natural-log amplitude, the decoder's output layout; the kernel
@@ -45,12 +47,12 @@ __global__ void __launch_bounds__(64 * kWaves) k_mel_to_mag(const float* __restr
     const int b = g / n_tblocks;
     const int t0 = ((g - b * n_tblocks) * kWaves + wave) * kTileT;
     const int f0 = ft * kTileF;
-    if (t0 >= T) return;  // wave-uniform
+    const bool active = t0 < T;   // wave-uniform; idle waves still take part in the barriers below
 
     const int li = lane & 31;
     const int lk = lane >> 5;
     const int t = t0 + li;
-    const bool t_ok = t < T;
+    const bool t_ok = active && t < T;
     const float* a_ptr = LOGMEL ? mel + ((long long)b * T + (t_ok ? t : 0)) * K
                                 : mel + (long long)b * K * T + (t_ok ? t : 0);
 
@@ -60,31 +62,51 @@ __global__ void __launch_bounds__(64 * kWaves) k_mel_to_mag(const float* __restr
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
 
-    bool f_ok[4];
-    int fidx[4];
+    // The filterbank tile of the workgroup (kKC bands x 128 bins) is staged in LDS once per K-chunk, laid
+    // out [k][j][4] so that the four B values a lane feeds to its four MFMAs are one ds_read_b128; the
+    // K loop then issues one coalesced global load (operand A) and one LDS read per step instead of five
+    // dependent global loads (the kernel spent 58 % of its wave time in s_waitcnt on those).
+    __shared__ __attribute__((aligned(16))) v4f Bs[kKC][32];
+    for (int kc = 0; kc < K; kc += kKC) {
+        // Operand A of the whole chunk goes to registers first (kKC/2 independent loads in flight while
+        // the workgroup stages B), so the MFMA loop below touches no global memory.
+        float av[kKC / 2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        int f = f0 + 32 * j + li;
-        f_ok[j] = f < F;
-        fidx[j] = f_ok[j] ? f : 0;
-    }
-
-#pragma unroll 8      // eight K-steps of loads in flight ahead of their MFMAs
-    for (int k0 = 0; k0 < K; k0 += 2) {
-        const int k = k0 + lk;
-        const bool k_ok = k < K;
-        const int kk = k_ok ? k : 0;
-        float a = LOGMEL ? expf(a_ptr[kk]) * inv_cf : a_ptr[(long long)kk * T];
-        a = (k_ok && t_ok) ? a : 0.0f;
-        float bv[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float v = fb[(long long)kk * F + fidx[j]];
-            bv[j] = (k_ok && f_ok[j]) ? v : 0.0f;
+        for (int s = 0; s < kKC / 2; ++s) {
+            const int k = kc + 2 * s + lk;
+            const bool ok = t_ok && k < K;
+            const int kk = ok ? k : 0;
+            const float a = LOGMEL ? a_ptr[kk] : a_ptr[(long long)kk * T];
+            av[s] = ok ? (LOGMEL ? expf(a) * inv_cf : a) : 0.0f;
         }
+        __syncthreads();
+        for (int e = threadIdx.x; e < kKC * 32; e += 64 * kWaves) {
+            const int k = e >> 5, jj = e & 31;
+            const bool k_ok = kc + k < K;
+            const float* row = fb + (long long)(k_ok ? kc + k : 0) * F;
+            v4f v;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[j], acc[j], 0, 0, 0);
+            for (int c = 0; c < 4; ++c) {
+                const int f = f0 + 32 * c + jj;
+                v[c] = (k_ok && f < F) ? row[f] : 0.0f;
+            }
+            Bs[k][jj] = v;
+        }
+        __syncthreads();
+        const int kend = min(kKC, K - kc);
+        if (active) {
+#pragma unroll
+            for (int s = 0; s < kKC / 2; ++s) {
+                if (2 * s < kend) {                          // wave-uniform; rows past K are zero in Bs and av
+                    const v4f bv = Bs[2 * s + lk][li];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[j], acc[j], 0, 0, 0);
+                }
+            }
+        }
     }
+    if (!active) return;
 
     float* out = mag + (long long)b * T * F;
 #pragma unroll

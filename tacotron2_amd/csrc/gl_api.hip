@@ -223,7 +223,7 @@ int gl_mel_to_mag(gl_plan* p, const float* filterbank, const float* mel, float* 
     if (n_mels < 1 || n_mels > 4096) return gl_set_error(GL_ERR_INVALID, "gl_mel_to_mag: n_mels=%d", n_mels);
     DeviceGuard guard(p->device);
     return gl_mel_launch(filterbank, mel, mag, n_mels, p->n_fft / 2 + 1, B, T, false, 1.0f,
-                         (p->opt_flags & GL_OPT_CLAMP_MAG) != 0, (hipStream_t)stream);
+                         (p->opt_flags & GL_OPT_CLAMP_MAG) != 0, p->n_cu, (hipStream_t)stream);
 }
 
 int gl_logmel_to_mag(gl_plan* p, const float* filterbank, const float* logmel, float* mag, int n_mels,
@@ -236,7 +236,7 @@ int gl_logmel_to_mag(gl_plan* p, const float* filterbank, const float* logmel, f
         return gl_set_error(GL_ERR_INVALID, "gl_logmel_to_mag: compression_factor must be > 0");
     DeviceGuard guard(p->device);
     return gl_mel_launch(filterbank, logmel, mag, n_mels, p->n_fft / 2 + 1, B, T, true, compression_factor,
-                         (p->opt_flags & GL_OPT_CLAMP_MAG) != 0, (hipStream_t)stream);
+                         (p->opt_flags & GL_OPT_CLAMP_MAG) != 0, p->n_cu, (hipStream_t)stream);
 }
 
 int gl_analysis_num_frames(int hop, long long len) {

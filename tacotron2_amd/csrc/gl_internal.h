@@ -77,7 +77,7 @@ int gl_fast_run(gl_plan* p, const float* mag, const float* x0, float* x_out, int
 
 // ---- mel inversion (MFMA): gl_mel.hip ---------------------------------------------
 int gl_mel_launch(const float* fb, const float* mel, float* mag, int n_mels, int F, int B, int T, bool logmel,
-                  float compression_factor, bool clamp, hipStream_t st);
+                  float compression_factor, bool clamp, int n_cu, hipStream_t st);
 
 int gl_mag_to_logmel_launch(const float* fb, const float* mag, float* logmel, int n_mels, int F, int B, int T,
                             float clip_min, float compression_factor, hipStream_t st);

@@ -16,107 +16,183 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 constexpr int kTileT = 32;      // rows (t) per wave
-constexpr int kTileF = 128;     // cols (f) per wave: 4 accumulators of 32
+constexpr int kNJ = 3;          // accumulators (32 bins each) per wave: F = 1025 is 33 blocks of 32 = 11 tiles of 3
+constexpr int kTileF = 32 * kNJ;
 constexpr int kWaves = 4;       // waves per workgroup, stacked along t
 constexpr int kKC = 80;         // mel bands per LDS stage of the filterbank tile (40 KB)
-typedef float v4f __attribute__((ext_vector_type(4)));
+// Resident workgroups per CU (3 waves per SIMD).  Measured on config 2 (64 x 861 frames, 80 bands): 109 us; 4 per
+// CU 105 us, 2 per CU with the next group's operand A prefetched into registers 123 us, 3 with prefetch 109 us
+// -- the other waves of the SIMD already cover the load latency.  Stores alone 44 us, MFMAs alone 84 us.
+constexpr int kWgPerCu = 3;
+
+// Buffer addressing: a wave-uniform base in a resource descriptor (scalar registers), one 32-bit lane
+// offset shared by every access of the tile, and a scalar offset per access -- the 40 operand loads and
+// 48 stores of a tile then need two address VGPRs instead of a 64-bit pointer pair each.
+constexpr int kRsrcBytes = 0x7fffffff;   // every access is in range by construction; no bounds masking
+constexpr int kRsrcFlags = 0x00020000;   // gfx9 raw buffer, 32-bit data format
+__device__ __forceinline__ float ld_buf(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+}
+__device__ __forceinline__ void st_buf(float v, __amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff, soff, 0);
+}
 
 // LOGMEL = false: mel is [B][K][T] linear amplitude (what save_mel_to_wav receives).
 // LOGMEL = true : mel is [B][T][K] natural-log amplitude, the decoder's output layout; the kernel
 //                 applies dynamic_range_decompression (data.py:84-85: exp(mel) / compression_factor)
 //                 and the transpose of infer.py:27-28 on the fly, so no (80, T) array is materialised.
-template <bool LOGMEL>
-__global__ void __launch_bounds__(64 * kWaves) k_mel_to_mag(const float* __restrict__ fb,
-                                                            const float* __restrict__ mel,
-                                                            float* __restrict__ mag, int K, int F, int T,
-                                                            float inv_cf, float floor_val, int n_ftiles,
-                                                            int n_tblocks, int n_groups) {
+//
+// A workgroup owns ONE tile of 96 bins for its whole life and walks over (utterance, 128-frame block)
+// groups: the filterbank tile (kKC bands x 96 bins) is staged in LDS once, laid out [k][j][4] so the
+// three B values a lane feeds to its three MFMAs are one ds_read_b128, and operand A of the NEXT group
+// (kKC/2 independent global loads) is fetched into registers while the MFMAs of the current one run, so
+// the MFMA loop touches no global memory.  n_mels > kKC falls back to restaging per group and chunk.
+//
+// XCD-aware order.  Workgroups go to the 8 XCDs round-robin by linear id, and a 128-byte store into the
+// 4100-byte rows rarely covers a whole cache line: xcd = id % 8 selects the groups (g % 8 == xcd), so
+// all F-tiles of one group run on one XCD, at the same pace, and their partial lines merge in that
+// XCD's L2 instead of leaving as partial writes from several.
+// FULLK: n_mels == kKC (80, the reference's n_mel_channels): one stage of B for the workgroup's life and a
+// branch-free K loop.  Otherwise B is restaged per group and chunk and every band is range-checked.
+template <bool LOGMEL, bool FULLK>
+__global__ void __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(kWgPerCu, kWgPerCu)))
+k_mel_to_mag(const float* __restrict__ fb, const float* __restrict__ mel, float* __restrict__ mag, int K, int F,
+             int T, float inv_cf, float floor_val, int n_ftiles, int n_tblocks, int n_groups, int n_slots) {
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    // XCD-aware tile order.  Workgroups go to the 8 XCDs round-robin by linear id, and a 128-byte
-    // store into the 4100-byte rows rarely covers a whole cache line: the F-tiles that share lines
-    // (same utterance, same frames) are given ids with equal id % 8, so they run on one XCD and
-    // their partial lines merge in that XCD's L2 instead of leaving as partial writes from several.
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // tells the compiler it is uniform
+    const int li = lane & 31;
+    const int lk = lane >> 5;
     const int id = blockIdx.x;
     const int q = id >> 3;
     const int ft = q % n_ftiles;
-    const int g = (q / n_ftiles) * 8 + (id & 7);        // (utterance, frame block)
-    if (g >= n_groups) return;                          // padding of the last group of eight
-    const int b = g / n_tblocks;
-    const int t0 = ((g - b * n_tblocks) * kWaves + wave) * kTileT;
+    const int slot = q / n_ftiles;
     const int f0 = ft * kTileF;
-    const bool active = t0 < T;   // wave-uniform; idle waves still take part in the barriers below
+    const int g_first = slot * 8 + (id & 7);
+    const int g_step = n_slots * 8;
 
-    const int li = lane & 31;
-    const int lk = lane >> 5;
-    const int t = t0 + li;
-    const bool t_ok = active && t < T;
-    const float* a_ptr = LOGMEL ? mel + ((long long)b * T + (t_ok ? t : 0)) * K
-                                : mel + (long long)b * K * T + (t_ok ? t : 0);
-
-    f32x16 acc[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
-
-    // The filterbank tile of the workgroup (kKC bands x 128 bins) is staged in LDS once per K-chunk, laid
-    // out [k][j][4] so that the four B values a lane feeds to its four MFMAs are one ds_read_b128; the
-    // K loop then issues one coalesced global load (operand A) and one LDS read per step instead of five
-    // dependent global loads (the kernel spent 58 % of its wave time in s_waitcnt on those).
     __shared__ __attribute__((aligned(16))) v4f Bs[kKC][32];
-    for (int kc = 0; kc < K; kc += kKC) {
-        // Operand A of the whole chunk goes to registers first (kKC/2 independent loads in flight while
-        // the workgroup stages B), so the MFMA loop below touches no global memory.
-        float av[kKC / 2];
-#pragma unroll
-        for (int s = 0; s < kKC / 2; ++s) {
-            const int k = kc + 2 * s + lk;
-            const bool ok = t_ok && k < K;
-            const int kk = ok ? k : 0;
-            const float a = LOGMEL ? a_ptr[kk] : a_ptr[(long long)kk * T];
-            av[s] = ok ? (LOGMEL ? expf(a) * inv_cf : a) : 0.0f;
-        }
-        __syncthreads();
+    auto stage_b = [&](int kc) {
         for (int e = threadIdx.x; e < kKC * 32; e += 64 * kWaves) {
             const int k = e >> 5, jj = e & 31;
             const bool k_ok = kc + k < K;
             const float* row = fb + (long long)(k_ok ? kc + k : 0) * F;
             v4f v;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < kNJ; ++c) {
                 const int f = f0 + 32 * c + jj;
                 v[c] = (k_ok && f < F) ? row[f] : 0.0f;
             }
+            v[3] = 0.0f;
             Bs[k][jj] = v;
         }
-        __syncthreads();
-        const int kend = min(kKC, K - kc);
-        if (active) {
+    };
+    // Operand A of group g, bands kc .. kc+kKC-1: lane (li, lk) holds band kc + 2 s + lk of frame t0 + li.
+    // Addresses are a wave-uniform base (scalar registers) plus one 32-bit lane offset shared by all loads.
+    auto load_a = [&](int g, int kc, float (&av)[kKC / 2]) {
+        const int b = g / n_tblocks;
+        const int t0 = ((g - b * n_tblocks) * kWaves + wave) * kTileT;
+        const bool t_ok = t0 + li < T;
+        const int lt = t_ok ? li : 0;                        // lanes past T read frame t0 and are zeroed
+        if (g >= n_groups || t0 >= T) {                      // wave-uniform: nothing of this tile exists, read nothing
 #pragma unroll
-            for (int s = 0; s < kKC / 2; ++s) {
-                if (2 * s < kend) {                          // wave-uniform; rows past K are zero in Bs and av
-                    const v4f bv = Bs[2 * s + lk][li];
+            for (int s = 0; s < kKC / 2; ++s) av[s] = 0.0f;
+            return;
+        }
+        const float* base = LOGMEL ? mel + ((long long)b * T + t0) * K + kc : mel + ((long long)b * K + kc) * T + t0;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, kRsrcBytes, kRsrcFlags);
+        const int k_stride = LOGMEL ? 1 : T;
+        const int lane_off = (LOGMEL ? lt * K + lk : lk * T + lt) * 4;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[j], acc[j], 0, 0, 0);
+        for (int s = 0; s < kKC / 2; ++s) {
+            if (FULLK) {
+                const float a = LOGMEL ? ld_buf(rs, lane_off + 8 * s, 0) : ld_buf(rs, lane_off, 8 * s * k_stride);
+                av[s] = t_ok ? (LOGMEL ? expf(a) * inv_cf : a) : 0.0f;
+            } else {
+                // kv = bands left from 2 s on (wave-uniform): >= 2 both half-waves load, 1 only lk = 0 has a
+                // band (the others read that band too and are zeroed), <= 0 nothing is read.
+                const int kv = K - kc - 2 * s;
+                float a = 0.0f;
+                if (kv >= 2) a = LOGMEL ? ld_buf(rs, lane_off + 8 * s, 0) : ld_buf(rs, lane_off, 8 * s * k_stride);
+                else if (kv == 1) a = LOGMEL ? ld_buf(rs, lane_off - 4 * lk + 8 * s, 0)
+                                             : ld_buf(rs, lane_off - 4 * lk * k_stride, 8 * s * k_stride);
+                av[s] = (t_ok && lk < kv) ? (LOGMEL ? expf(a) * inv_cf : a) : 0.0f;
+            }
+        }
+    };
+    auto mfma_chunk = [&](f32x16 (&acc)[kNJ], const float (&av)[kKC / 2], int kend) {
+#pragma unroll
+        for (int s = 0; s < kKC / 2; ++s) {
+            if (FULLK || 2 * s < kend) {                     // wave-uniform; rows past K are zero in Bs and av
+                const v4f bv = Bs[2 * s + lk][li];
+#pragma unroll
+                for (int j = 0; j < kNJ; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[j], acc[j], 0, 0, 0);
+            }
+            // Without a fence the scheduler hoists all 40 ds_read_b128 (160 VGPRs) above the first MFMA.
+            if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto store = [&](int g, const f32x16 (&acc)[kNJ]) {
+        const int b = g / n_tblocks;
+        const int t0 = ((g - b * n_tblocks) * kWaves + wave) * kTileT;
+        if (t0 >= T) return;
+        float* base = mag + ((long long)b * T + t0) * F + f0;   // wave-uniform
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, kRsrcBytes, kRsrcFlags);
+        const int lane_off = (4 * lk * F + li) * 4;
+        const bool full = t0 + kTileT <= T && f0 + kTileF <= F;
+        if (full) {
+#pragma unroll
+            for (int j = 0; j < kNJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    st_buf(fmaxf(acc[j][r], floor_val), rs, lane_off, (((r & 3) + 8 * (r >> 2)) * F + 32 * j) * 4);
+        } else {
+#pragma unroll
+            for (int j = 0; j < kNJ; ++j) {
+                if (f0 + 32 * j + li >= F) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ro = (r & 3) + 8 * (r >> 2);
+                    if (t0 + ro + 4 * lk < T)
+                        st_buf(fmaxf(acc[j][r], floor_val), rs, lane_off, (ro * F + 32 * j) * 4);  // -inf: no clamp
                 }
             }
         }
-    }
-    if (!active) return;
+    };
+    auto zero = [&](f32x16 (&acc)[kNJ]) {
+#pragma unroll
+        for (int j = 0; j < kNJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    };
 
-    float* out = mag + (long long)b * T * F;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int f = f0 + 32 * j + li;
-        if (f >= F) continue;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = t0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            if (row < T) out[(long long)row * F + f] = fmaxf(acc[j][r], floor_val);   // -inf: no clamp
+    if (FULLK) {
+        stage_b(0);
+        __syncthreads();
+        for (int g = g_first; g < n_groups; g += g_step) {
+            float av[kKC / 2];
+            load_a(g, 0, av);
+            f32x16 acc[kNJ];
+            zero(acc);
+            mfma_chunk(acc, av, K);
+            store(g, acc);
+        }
+    } else {
+        for (int g = g_first; g < n_groups; g += g_step) {   // workgroup-uniform trip count
+            f32x16 acc[kNJ];
+            zero(acc);
+            for (int kc = 0; kc < K; kc += kKC) {
+                float av[kKC / 2];
+                load_a(g, kc, av);
+                __syncthreads();
+                stage_b(kc);
+                __syncthreads();
+                mfma_chunk(acc, av, min(kKC, K - kc));
+            }
+            store(g, acc);
         }
     }
 }
@@ -186,18 +262,21 @@ int gl_mag_to_logmel_launch(const float* fb, const float* mag, float* logmel, in
 }
 
 int gl_mel_launch(const float* fb, const float* mel, float* mag, int n_mels, int F, int B, int T, bool logmel,
-                  float compression_factor, bool clamp, hipStream_t st) {
+                  float compression_factor, bool clamp, int n_cu, hipStream_t st) {
     const float floor_val = clamp ? 0.0f : -INFINITY;     // GL_OPT_CLAMP_MAG (pseudo-inverse bases go negative)
     const int n_ftiles = (F + kTileF - 1) / kTileF;
     const int n_tblocks = (T + kTileT * kWaves - 1) / (kTileT * kWaves);
     const int n_groups = n_tblocks * B;
-    dim3 grid((unsigned)(((n_groups + 7) / 8) * 8 * n_ftiles));
-    if (logmel)
-        hipLaunchKernelGGL(k_mel_to_mag<true>, grid, dim3(64 * kWaves), 0, st, fb, mel, mag, n_mels, F, T,
-                           1.0f / compression_factor, floor_val, n_ftiles, n_tblocks, n_groups);
-    else
-        hipLaunchKernelGGL(k_mel_to_mag<false>, grid, dim3(64 * kWaves), 0, st, fb, mel, mag, n_mels, F, T, 1.0f,
-                           floor_val, n_ftiles, n_tblocks, n_groups);
+    // One round of resident workgroups: per XCD (n_cu / 8 CUs) kWgPerCu per CU, shared by the F-tiles.
+    int n_slots = (n_cu / 8) * kWgPerCu / n_ftiles;
+    if (n_slots < 1) n_slots = 1;
+    if (n_slots > (n_groups + 7) / 8) n_slots = (n_groups + 7) / 8;
+    dim3 grid((unsigned)(8 * n_ftiles * n_slots));
+    const float inv_cf = logmel ? 1.0f / compression_factor : 1.0f;
+    auto kern = logmel ? (n_mels == kKC ? k_mel_to_mag<true, true> : k_mel_to_mag<true, false>)
+                       : (n_mels == kKC ? k_mel_to_mag<false, true> : k_mel_to_mag<false, false>);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * kWaves), 0, st, fb, mel, mag, n_mels, F, T, inv_cf, floor_val, n_ftiles,
+                       n_tblocks, n_groups, n_slots);
     GL_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -192,8 +192,11 @@ def test_mel_to_mag_golden(golden):
 
 
 def test_mel_to_mag_ragged_shapes():
+    """Band counts either side of the 80-band stage (7, 79, 81, 160, 163: partial, odd and multi-chunk K),
+    frame counts that leave partial tiles, and a batch with more frame groups than resident workgroups."""
     rng = np.random.default_rng(3)
-    for N, n_mels, T, B in [(1024, 80, 1, 1), (1024, 80, 33, 2), (2048, 80, 129, 3), (64, 7, 5, 2), (2048, 81, 31, 1)]:
+    for N, n_mels, T, B in [(1024, 80, 1, 1), (1024, 80, 33, 2), (2048, 80, 129, 3), (64, 7, 5, 2), (2048, 81, 31, 1),
+                            (1024, 79, 140, 9), (2048, 160, 300, 2), (512, 163, 70, 3), (256, 80, 128, 700)]:
         F = N // 2 + 1
         fb = np.abs(rng.standard_normal((n_mels, F))).astype(np.float32)
         mel = np.abs(rng.standard_normal((B, n_mels, T))).astype(np.float32)
@@ -201,6 +204,11 @@ def test_mel_to_mag_ragged_shapes():
         got = p.mel_to_mag(torch.from_numpy(fb).cuda(), torch.from_numpy(mel).cuda()).cpu().numpy()
         ref = np.einsum("mf,bmt->btf", fb.astype(np.float64), mel.astype(np.float64))
         assert peak_err(got, ref) <= 1e-6, (N, n_mels, T, B)
+        # the decoder-layout entry point ((B, T, n_mels) log amplitude) takes the same paths
+        lm = np.log(np.maximum(mel, 1e-3)).transpose(0, 2, 1).copy()
+        got = p.logmel_to_mag(torch.from_numpy(fb).cuda(), torch.from_numpy(lm).cuda(), 1.5).cpu().numpy()
+        ref = np.einsum("mf,btm->btf", fb.astype(np.float64), np.exp(lm.astype(np.float64)) / 1.5)
+        assert peak_err(got, ref) <= 2e-6, (N, n_mels, T, B)
         p.close()
 
 

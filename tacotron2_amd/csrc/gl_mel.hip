@@ -200,48 +200,106 @@ k_mel_to_mag(const float* __restrict__ fb, const float* __restrict__ mel, float*
 // N3  data.py:112-114: mel = filterbank @ |stft|, log(clip(mel, 0.01) * compression_factor).
 //     logmel[b][m][t] = log(max(sum_f fb[m][f] * mag[b][t][f], clip_min) * cf)
 // C[m x t] = A[m x f] * B[f x t] with i = m, j = t: the accumulator's 32 lanes of one register are 32
-// consecutive t of one mel band, so the (B, n_mels, T) output is stored coalesced.  One wave owns
-// 32 frames and all mel bands (kMelTiles accumulators of 32 bands); K = F runs two bins per MFMA.
-constexpr int kMelTiles = 4;     // up to 128 mel bands
+// consecutive t of one mel band, so the (B, n_mels, T) output is stored coalesced.  One wave owns 32
+// frames and all mel bands (TILES accumulators of 32 bands); K = F runs two bins per MFMA.
+//
+// Both operands are contiguous in f, the contraction index, so they are staged through LDS: per chunk of
+// kFC bins the workgroup copies fb[0..32 TILES)[f0..f0+kFC) and mag[t0..t0+128)[f0..f0+kFC) with
+// 16-byte loads (8 lanes cover the 128 bytes of one row's chunk) into rows padded to kFC + 1 floats, which
+// makes the MFMA operand reads (32 rows at one f) conflict-free.  The global loads of chunk c + 1 are
+// issued before the MFMAs of chunk c and written to LDS after them.
+constexpr int kFC = 32;                       // bins per chunk
+constexpr int kFS = kFC + 1;                  // LDS row stride in floats
+typedef float v4f_u __attribute__((ext_vector_type(4), aligned(4)));   // rows are 4 F bytes apart: 4-byte aligned
+template <int TILES>
 __global__ void __launch_bounds__(64 * kWaves) k_mag_to_logmel(const float* __restrict__ fb,
                                                                const float* __restrict__ mag,
                                                                float* __restrict__ logmel, int n_mels, int F, int T,
                                                                float clip_min, float cf) {
+    constexpr int kRowsA = 32 * TILES;        // filterbank rows staged (rows >= n_mels are zero)
+    constexpr int kRowsB = 32 * kWaves;       // frames staged
+    constexpr int kQuads = (kRowsA + kRowsB) * (kFC / 4) / (64 * kWaves);   // 16-byte pieces per thread and chunk
+    static_assert((kRowsA + kRowsB) * (kFC / 4) % (64 * kWaves) == 0, "staging must divide evenly");
+    __shared__ float As[kRowsA * kFS];
+    __shared__ float Bs[kRowsB * kFS];
+
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.y;
-    const int t0 = (blockIdx.x * kWaves + wave) * 32;
-    if (t0 >= T) return;  // wave-uniform
+    const int t_blk = blockIdx.x * kRowsB;    // first frame of the workgroup
     const int li = lane & 31;
     const int lk = lane >> 5;
-    const int t = t0 + li;
-    const bool t_ok = t < T;
-    const float* b_ptr = mag + ((long long)b * T + (t_ok ? t : 0)) * F;
-    const int tiles = (n_mels + 31) / 32;
-    f32x16 acc[kMelTiles];
+    const float* mag_b = mag + (long long)b * T * F;
+
+    // Piece q of this thread: row (A rows first, then B rows) and the quad of 4 bins inside the chunk.
+    auto piece = [&](int q, int& row, int& c4) {
+        const int e = q * 64 * kWaves + threadIdx.x;
+        row = e >> 3;
+        c4 = (e & 7) * 4;
+    };
+    auto fetch = [&](int f0, v4f (&regs)[kQuads]) {
 #pragma unroll
-    for (int j = 0; j < kMelTiles; ++j)
+        for (int q = 0; q < kQuads; ++q) {
+            int row, c4;
+            piece(q, row, c4);
+            const bool is_a = row < kRowsA;                  // uniform per wave: kRowsA is a multiple of 8 rows x 8 lanes
+            const int r = is_a ? row : row - kRowsA;
+            const bool row_ok = is_a ? r < n_mels : t_blk + r < T;
+            const float* src = is_a ? fb + (long long)r * F : mag_b + (long long)(t_blk + r) * F;
+            const int f = f0 + c4;
+            v4f v = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (row_ok) {
+                if (f + 4 <= F) {
+                    v = *reinterpret_cast<const v4f_u*>(src + f);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (f + c < F) v[c] = src[f + c];
+                }
+            }
+            regs[q] = v;
+        }
+    };
+    auto deposit = [&](const v4f (&regs)[kQuads]) {
+#pragma unroll
+        for (int q = 0; q < kQuads; ++q) {
+            int row, c4;
+            piece(q, row, c4);
+            float* dst = row < kRowsA ? As + row * kFS + c4 : Bs + (row - kRowsA) * kFS + c4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dst[c] = regs[q][c];
+        }
+    };
+
+    f32x16 acc[TILES];
+#pragma unroll
+    for (int j = 0; j < TILES; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
-    for (int k0 = 0; k0 < F; k0 += 2) {
-        const int k = k0 + lk;
-        const bool k_ok = k < F;
-        const int kk = k_ok ? k : 0;
-        const float bv = (k_ok && t_ok) ? b_ptr[kk] : 0.0f;
+
+    v4f regs[kQuads];
+    fetch(0, regs);
+    for (int f0 = 0; f0 < F; f0 += kFC) {
+        __syncthreads();                                     // the previous chunk has been consumed
+        deposit(regs);
+        __syncthreads();
+        if (f0 + kFC < F) fetch(f0 + kFC, regs);             // in flight during the MFMAs below
+        const float* bp = Bs + (wave * 32 + li) * kFS + lk;
+        const float* ap = As + li * kFS + lk;
 #pragma unroll
-        for (int j = 0; j < kMelTiles; ++j) {
-            if (j < tiles) {
-                const int m = 32 * j + li;
-                const float av = (k_ok && m < n_mels) ? fb[(long long)m * F + kk] : 0.0f;
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
-            }
+        for (int k = 0; k < kFC; k += 2) {
+            const float bv = bp[k];
+#pragma unroll
+            for (int j = 0; j < TILES; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[j * 32 * kFS + k], bv, acc[j], 0, 0, 0);
         }
     }
+
+    const int t = t_blk + wave * 32 + li;
+    if (t >= T) return;
     float* out = logmel + (long long)b * n_mels * T;
-    if (!t_ok) return;
 #pragma unroll
-    for (int j = 0; j < kMelTiles; ++j) {
-        if (j >= tiles) continue;
+    for (int j = 0; j < TILES; ++j) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = 32 * j + (r & 3) + 8 * (r >> 2) + 4 * lk;
@@ -255,7 +313,11 @@ __global__ void __launch_bounds__(64 * kWaves) k_mag_to_logmel(const float* __re
 int gl_mag_to_logmel_launch(const float* fb, const float* mag, float* logmel, int n_mels, int F, int B, int T,
                             float clip_min, float compression_factor, hipStream_t st) {
     dim3 grid((T + 32 * kWaves - 1) / (32 * kWaves), B);
-    hipLaunchKernelGGL(k_mag_to_logmel, grid, dim3(64 * kWaves), 0, st, fb, mag, logmel, n_mels, F, T, clip_min,
+    const int tiles = (n_mels + 31) / 32;
+    if (tiles < 1 || tiles > 4) return gl_set_error(GL_ERR_INVALID, "mag_to_logmel: n_mels=%d outside [1, 128]", n_mels);
+    auto kern = tiles == 1 ? k_mag_to_logmel<1> : tiles == 2 ? k_mag_to_logmel<2> : tiles == 3 ? k_mag_to_logmel<3>
+                                                                                               : k_mag_to_logmel<4>;
+    hipLaunchKernelGGL(kern, grid, dim3(64 * kWaves), 0, st, fb, mag, logmel, n_mels, F, T, clip_min,
                        compression_factor);
     GL_HIP_CHECK(hipGetLastError());
     return 0;

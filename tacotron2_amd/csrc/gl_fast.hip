@@ -667,6 +667,14 @@ __device__ __forceinline__ void twiddle2(v2f* z, const TAB& tb, const v2f* w2r) 
     }
 }
 // exchange 1: register k2 <-> lane bits g3.  "cols" side: 16 x b64 at pi(l); "rows" side: 2 x 4 x b128
+// GL_PIN_READS (experiment, off): bit mask of transposes (1 ex1 rows, 2 ex1 cols, 4 ex2 cols, 8 ex2 rows) whose
+// reads get a scheduling fence behind them, so that all 16 are issued right after the writes instead of being
+// sunk to their first use (the compiler sinks them to save registers).  Config 2: 1 and 2 -1 % (noise), 4 +1.7 %,
+// 8 +0.7 %, all four +4 % (246 VGPRs, no spills): the fence costs other reorderings more than the earlier issue gains.
+#ifndef GL_PIN_READS
+#define GL_PIN_READS 0
+#endif
+#define GL_PIN(bit) do { if (GL_PIN_READS & (bit)) __builtin_amdgcn_sched_barrier(0); } while (0)
 __device__ __forceinline__ void ex1_put_cols(const v2f* z, v2f* ex, const LanePos& lp) {
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -679,6 +687,7 @@ __device__ __forceinline__ void ex1_get_rows(v2f* z, const v2f* ex, const LanePo
 #pragma unroll
         for (int bb = 0; bb < 8; bb += 2)
             lds_rd_pair(&ex[(lp.g3 + 8 * h) * kE1S + lp.a3 * kE1P + bb], z[8 * h + bb], z[8 * h + bb + 1]);
+    GL_PIN(1);
 }
 __device__ __forceinline__ void ex1_put_rows(const v2f* z, v2f* ex, const LanePos& lp) {
     __builtin_amdgcn_wave_barrier();
@@ -692,6 +701,7 @@ __device__ __forceinline__ void ex1_put_rows(const v2f* z, v2f* ex, const LanePo
 __device__ __forceinline__ void ex1_get_cols(v2f* z, const v2f* ex, const LanePos& lp) {
 #pragma unroll
     for (int k2 = 0; k2 < 16; ++k2) z[k2] = lds_rd(&ex[k2 * kE1S + lp.piL]);
+    GL_PIN(2);
 }
 // exchange 2: register d <-> lane bits a3.  "rows" side: 2 x 4 x b128; "cols" side: 16 x b64 at rho(l), rho(128-l)
 __device__ __forceinline__ void ex2_put_rows(const v2f* z, v2f* ex, const LanePos& lp) {
@@ -706,6 +716,7 @@ __device__ __forceinline__ void ex2_put_rows(const v2f* z, v2f* ex, const LanePo
 __device__ __forceinline__ void ex2_get_cols(v2f* z, const v2f* ex, const LanePos& lp) {
 #pragma unroll
     for (int a = 0; a < 8; ++a) { z[a] = lds_rd(&ex[a * kE2S + lp.rhoL]); z[8 + a] = lds_rd(&ex[a * kE2S + lp.rhoK]); }
+    GL_PIN(4);
 }
 __device__ __forceinline__ void ex2_put_cols(const v2f* z, v2f* ex, const LanePos& lp) {
     __builtin_amdgcn_wave_barrier();
@@ -719,6 +730,7 @@ __device__ __forceinline__ void ex2_get_rows(v2f* z, const v2f* ex, const LanePo
 #pragma unroll
         for (int d = 0; d < 8; d += 2)
             lds_rd_pair(&ex[lp.a3 * kE2S + (lp.g3 + 8 * h) * kE2Q + d], z[8 * h + d], z[8 * h + d + 1]);
+    GL_PIN(8);
 }
 
 template <class TAB>

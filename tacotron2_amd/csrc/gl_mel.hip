@@ -7,10 +7,12 @@
 //
 // v_mfma_f32_32x32x2_f32: lane l supplies A[i = l&31][k = l>>5] and
 // B[k = l>>5][j = l&31]; the accumulator holds col = l&31,
-// row = (reg&3) + 8*(reg>>2) + 4*(l>>5).  With i = t and j = f both operand loads
-// and the C stores are contiguous across lanes, so no LDS staging is needed; the
-// output is written directly in the (B, T, F) row-major layout the Griffin-Lim
-// kernels read.  The result is bit-for-bit an fp32 fma chain over m = 0..K-1.
+// row = (reg&3) + 8*(reg>>2) + 4*(l>>5).  With i = t and j = f the C stores are contiguous
+// across lanes and the output is written directly in the (B, T, F) row-major layout the
+// Griffin-Lim kernels read.  The result is bit-for-bit an fp32 fma chain over m = 0..K-1.
+// The filterbank tile is staged in LDS once per workgroup, operand A goes to registers
+// per frame group (see k_mel_to_mag).  The forward product of the analysis path
+// (k_mag_to_logmel, N3) is in this file too.
 #include "gl_internal.h"
 
 namespace {

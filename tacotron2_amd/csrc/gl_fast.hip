@@ -14,6 +14,7 @@
 //   k_gl2048_regring<HS> n_fft 2048, hop 128*HS: rings in registers, two frames in flight per wave
 //                        (the benchmark kernel)
 //   k_gl1024_pair / k_gl1024_pair2   n_fft 1024, any hop: two real frames per complex FFT
+//   k_analysis2048       n_fft 2048: |centred STFT| of the forward analysis path (wav -> log-mel), one wave per frame
 // The FFT core (dft16/dft8, twiddle1/2, ex1_*/ex2_* transposes, middle_project) is shared.
 //
 // The index decomposition n = a + 8b + 64 n2, k = k2 + 16 d + 128 c and the lane
@@ -1694,6 +1695,90 @@ int ensure_buffers(gl_plan* p) {
     return rc;
 }
 
+// =====================================================================================
+// N3 forward analysis, n_fft 2048 (data.py:110-111: np.abs(librosa.stft(y, n_fft))): centred frames at any
+// hop, periodic Hann, |rfft|.  One wave per frame on the register FFT core (same passes and mirror-pair
+// split as the Griffin-Lim kernels), frames dealt to the waves of one resident round; the centre padding
+// (reflect, or zeros) is folded into the frame gather of the few edge frames.
+struct AnalysisArgs {
+    const float* y;          // [B][y_stride], len valid samples each
+    long long y_stride, len;
+    float* mag;              // [B][T][1025]
+    const v2f* tab;          // [kT2Entries][64]
+    const float* win_p;      // periodic Hann, 2048 floats
+    int H, T, reflect;
+    long long n_frames;      // B * T
+};
+typedef float v2f_u __attribute__((ext_vector_type(2), aligned(4)));   // frame starts are only 4-byte aligned
+
+__global__ void __launch_bounds__(64 * kRRWaves) k_analysis2048(AnalysisArgs p) {
+    __shared__ __attribute__((aligned(16))) v2f smem[kT2Entries * 64 + kRRWaves * kRScratch];
+    const int l = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i = threadIdx.x; i < kT2Entries * 64; i += 64 * kRRWaves) smem[i] = p.tab[i];
+    __syncthreads();                             // no barrier after this point
+    v2f* ex = smem + kT2Entries * 64 + wave * kRScratch;
+    const TabLds tb{smem + 2 * l};
+    const int a3 = l & 7, g3 = l >> 3;
+    const int kloB = l ? 128 - l : 64;
+    const bool l0 = (l == 0);
+    v2f win[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) win[j] = *reinterpret_cast<const v2f*>(p.win_p + 2 * (l + 64 * j));
+    Stamps st;
+    st.start();
+    const long long step = (long long)gridDim.x * kRRWaves;
+    for (long long fr = (long long)blockIdx.x * kRRWaves + wave; fr < p.n_frames; fr += step) {
+        const int b = (int)(fr / p.T);
+        const int t = (int)(fr - (long long)b * p.T);
+        const float* yr = p.y + (long long)b * p.y_stride;
+        const long long s0 = (long long)t * p.H - kM;
+        v2f z[16];
+        if (s0 >= 0 && s0 + kN <= p.len) {       // wave-uniform: the frame lies inside the signal
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const v2f_u v = *reinterpret_cast<const v2f_u*>(yr + s0 + 2 * (l + 64 * j));
+                z[j] = (v2f){v.x, v.y} * win[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                float v[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    long long sidx = s0 + 2 * (l + 64 * j) + e;
+                    bool inside = (sidx >= 0 && sidx < p.len);
+                    if (!inside && p.reflect) {
+                        sidx = sidx < 0 ? -sidx : 2 * (p.len - 1) - sidx;
+                        inside = (sidx >= 0 && sidx < p.len);
+                    }
+                    v[e] = inside ? yr[sidx] : 0.0f;
+                }
+                z[j] = (v2f){v[0], v[1]} * win[j];
+            }
+        }
+        fft_forward_1024(z, ex, l, a3, g3, kloB, tb, st);
+        // mirror-pair split (see middle_project): 2 X[k] = (P + conj Q) + w (P - conj Q), 2 conj X[M-k] = ... - ...
+        float* orow = p.mag + fr * (kM + 1);
+        const v2f z4 = z[4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            v2f P, Q;
+            if (u == 0) { P = z[0]; Q = sel(l0, z[0], z[15]); }
+            else if (u < 4) { P = z[u]; Q = sel(l0, z[8 - u], z[15 - u]); }
+            else { P = sel(l0, z[8 + u - 4], z[u]); Q = sel(l0, z[8 + 11 - u], z[15 - u]); }
+            const v2f w = tb.get(kT2Twp + u);
+            const v2f uu = pk_addc(P, Q), vv = pk_subc(P, Q);
+            const v2f X = cmul_add(vv, w, uu), Y = cmul_sub(vv, w, uu);
+            const int k = l ? l + 128 * u : (u < 4 ? 128 * u : 64 + 128 * (u - 4));
+            orow[k] = 0.5f * sqrtf(fmaf(X.x, X.x, X.y * X.y));
+            orow[kM - k] = 0.5f * sqrtf(fmaf(Y.x, Y.x, Y.y * Y.y));
+        }
+        if (l0) orow[512] = sqrtf(fmaf(z4.x, z4.x, z4.y * z4.y));   // bin 512 is its own mirror
+    }
+    st.flush(l);
+}
+
 template <int MODE>
 int launch(const FastArgs& a, int B, hipStream_t st) {
     dim3 grid(a.nruns, B);
@@ -1973,6 +2058,29 @@ int gl_fast_istft(gl_plan* p, const float* S, float* y, int B, int T, hipStream_
     rc = launch<MODE_ISTFT>(a, B, st);
     if (rc || a.nruns == 1) return rc;
     return fold(p, p->d_xa, p->d_tail_a, y, B, T, a.G, a.nruns, st);
+}
+
+// N3: |centred STFT| of B signals (n_fft 2048 only; gl_analysis_mag is the any-N path)
+int gl_fast_analysis_mag(gl_plan* p, const float* y, long long y_stride, long long len, float* mag, int reflect,
+                         int B, int T, const float* win_p, hipStream_t st) {
+    int rc = ensure_table2(p);
+    if (rc) return rc;
+    AnalysisArgs a = {};
+    a.y = y;
+    a.y_stride = y_stride;
+    a.len = len;
+    a.mag = mag;
+    a.tab = reinterpret_cast<const v2f*>(p->d_fast_tab2);
+    a.win_p = win_p;
+    a.H = p->hop;
+    a.T = T;
+    a.reflect = reflect;
+    a.n_frames = (long long)B * T;
+    long long wgs = (a.n_frames + kRRWaves - 1) / kRRWaves;
+    if (wgs > p->n_cu) wgs = p->n_cu;            // one resident round; the waves walk the frames
+    hipLaunchKernelGGL(k_analysis2048, dim3((unsigned)wgs), dim3(64 * kRRWaves), 0, st, a);
+    GL_HIP_CHECK(hipGetLastError());
+    return 0;
 }
 
 int gl_fast_run(gl_plan* p, const float* mag, const float* x0, float* x_out, int iters, int B, int T,

@@ -258,6 +258,9 @@ int gl_analysis_mag(gl_plan* p, const float* y, long long y_stride, long long le
         if (rc) return rc;
         GL_HIP_CHECK(hipMemcpy(p->d_window_p, w.data(), sizeof(float) * N, hipMemcpyHostToDevice));
     }
+    // n_fft 2048 on the fused path: one wave per frame on the register FFT core (gl_fast.hip)
+    if (p->path == 0 && N == 2048 && gl_fast_supported(p, GL_FAST_OP_STFT))
+        return gl_fast_analysis_mag(p, y, y_stride, len, mag, reflect, B, T, p->d_window_p, st);
     size_t lds = (size_t)N * sizeof(float2);
     hipLaunchKernelGGL(k_analysis_mag, dim3(T, B), dim3(kThreads), lds, st, y, y_stride, len, mag, p->d_window_p,
                        p->d_tw, N, p->hop, T, reflect);

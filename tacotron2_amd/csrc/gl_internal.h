@@ -72,6 +72,8 @@ int gl_post_iter(gl_plan* p, const float* x_main, const float* tail, float* out,
 int gl_ensure_options(gl_plan* p, int T);   // allocations / tables the options need for T frames
 int gl_fast_stft(gl_plan* p, const float* x, long long x_stride, float* S, int B, int T, hipStream_t st);
 int gl_fast_istft(gl_plan* p, const float* S, float* y, int B, int T, hipStream_t st);
+int gl_fast_analysis_mag(gl_plan* p, const float* y, long long y_stride, long long len, float* mag, int reflect,
+                         int B, int T, const float* win_p, hipStream_t st);
 int gl_fast_run(gl_plan* p, const float* mag, const float* x0, float* x_out, int iters, int B, int T,
                 hipStream_t st);
 

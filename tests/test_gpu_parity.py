@@ -523,7 +523,8 @@ def test_variant_istft_normalised_inverts_stft_and_pinv_basis_clamps():
 # ---- N3: forward analysis path (data.py:100-116); librosa parity unpinned, numpy statement of its algorithm ----
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_fft,hop,n,pad", [(1024, None, 22050, "reflect"), (1024, None, 9000, "constant"),
-                                             (2048, 256, 30000, "reflect"), (1024, 275, 7777, "reflect")])
+                                             (2048, 256, 30000, "reflect"), (1024, 275, 7777, "reflect"),
+                                             (2048, None, 30011, "constant"), (2048, 301, 5000, "reflect")])
 def test_analysis_wav_to_logmel(n_fft, hop, n, pad):
     from tacotron2_amd import analysis, filters
     rng = np.random.default_rng(51)
@@ -543,6 +544,26 @@ def test_analysis_wav_to_logmel(n_fft, hop, n, pad):
         assert np.max(np.abs(lm[b] - ref_lm)) <= 2e-4
     one = analysis.audio_to_mel(y, n_fft=n_fft, hop=hop, filterbank=fb, pad_mode=pad, device="cuda:0")
     assert one.shape == (80, 1 + n // h) and np.array_equal(one, lm[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pad", ["reflect", "constant"])
+def test_analysis_fused_and_generic_kernels_agree(pad):
+    """n_fft 2048 has two implementations of |centred STFT| (one wave per frame on the register FFT, and the
+    any-N workgroup-per-frame kernel): same numbers on a batch whose signals are shorter than the row stride."""
+    n, B, N, H = 20000, 3, 2048, 512
+    rng = np.random.default_rng(57)
+    y = torch.from_numpy((0.3 * rng.standard_normal((B, n + 37))).astype(np.float32)).cuda()[:, :n]
+    fb = torch.from_numpy(filters.mel(22050, N, 80, 125, 7600)).cuda()
+    out = []
+    for path in (0, 1):
+        p = Plan(N, H, 1 + n // H, B)
+        p.set_path(path)
+        lm, mag = p.wav_to_logmel(y.contiguous(), fb, pad_mode=pad)
+        out.append((lm.cpu().numpy(), mag.cpu().numpy()))
+        p.close()
+    assert np.max(np.abs(out[0][1] - out[1][1])) <= 2e-5 * np.max(out[1][1])
+    assert np.max(np.abs(out[0][0] - out[1][0])) <= 2e-4
 
 
 @pytest.mark.gpu

@@ -32,6 +32,7 @@ import torch  # noqa: E402
 
 SR = 22050
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
+VALU_FP32_PEAK_TF = 157.3 # MI355X_MICROARCH.md: packed fp32 vector peak (256 CUs x 256 flop/clk x 2.4 GHz)
 
 
 def synth_mels(B, T, seed):
@@ -69,6 +70,30 @@ def cpu_baseline(N, H, T, iters, budget_s):
             "host_cpus": os.cpu_count()}
 
 
+def cpu_baseline_all_cores(N, H, T, iters, budget_s, per_utt_s):
+    """the same loop form, one utterance per process, on every host core this job may use
+    (16 per GPU on the pool's boxes; os.cpu_count() there reports the whole machine)."""
+    import subprocess
+    cores = int(max(1, min(16, os.cpu_count() or 1)))
+    reps = int(max(1, min(8, budget_s / max(per_utt_s, 1e-6))))
+    env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
+    worker = os.path.join(ROOT, "oracle", "cpu_worker.py")
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen([sys.executable, worker, str(N), str(H), str(T), str(iters), str(reps), str(100 + i)],
+                              stdout=subprocess.PIPE, env=env, text=True) for i in range(cores)]
+    secs = []
+    for pr in procs:
+        out, _ = pr.communicate(timeout=600)
+        if pr.returncode != 0:
+            return {"error": f"worker exit {pr.returncode}"}
+        secs.append(float(out.strip().splitlines()[-1]))
+    wall = time.perf_counter() - t0
+    audio_s = (T * H + N) / SR
+    return {"value": cores * reps * audio_s / max(secs), "unit": "audio-s/s", "cores": cores, "kind": "port",
+            "sample": f"{cores} processes x {reps} utterances x {iters} iterations, single-threaded each "
+                      f"(slowest worker {max(secs):.1f} s, fastest {min(secs):.1f} s, {wall:.1f} s incl. start-up)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -92,6 +117,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    all_cores = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -105,6 +131,9 @@ def main():
         else:
             dist.init_process_group(backend)
     else:
+        # the all-cores CPU leg starts child processes: run it before this process touches the GPU
+        if args.cpu_seconds > 0:
+            all_cores = cpu_baseline_all_cores(args.n_fft, args.hop, args.frames, args.iters, args.cpu_seconds, 4.0)
         torch.cuda.set_device(0)
     n_gpus = world if world > 1 else 1
     if args.gpus != n_gpus and rank == 0:
@@ -195,6 +224,10 @@ def main():
         iter_ms = sum(a.elapsed_time(b) for a, b in gl_ms) / (len(gl_ms) * K)
         algo_bytes = B * (T * F * 4 + 2 * L * 4)          # read mag + read x + write x
         achieved = algo_bytes / (iter_ms * 1e-3) / 1e9
+        # SURVEY 8d flop count of one iteration (radix-2 convention 2.5 N log2 N per real FFT, windows,
+        # projection at 8 flop/bin, overlap-add): the fused loop sits at the HBM/VALU ridge, so both are reported
+        algo_flops = B * (2 * T * 2.5 * N * np.log2(N) + 2 * T * N + 8 * T * F + T * N)
+        valu_tf = algo_flops / (iter_ms * 1e-3) / 1e12
         default_cfg = (N, H, T, B, K) == (2048, 256, 861, 64, 60)
         workload = ("BASELINE config 2: batch of 64 synthetic 10 s 80-band mels per GPU, "
                     "mel->linear + Griffin-Lim 60 iters + peak normalise") if default_cfg else (
@@ -222,12 +255,17 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "fused Griffin-Lim iteration (gl_run, one launch per iteration)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": iter_ms},
+                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": iter_ms,
+                         "valu_fp32": {"achieved": valu_tf, "peak": VALU_FP32_PEAK_TF, "unit": "TFLOP/s",
+                                       "frac": valu_tf / VALU_FP32_PEAK_TF,
+                                       "algorithmic_flops_per_launch": float(algo_flops)}},
             "outputs_finite": finite,
             "hipgraph_ms_per_step": graph_ms,
         }
         if args.cpu_seconds > 0 and n_gpus == 1:
             out["cpu_baseline"] = cpu_baseline(N, H, T, K, args.cpu_seconds)
+            if all_cores is not None:
+                out["cpu_baseline"]["all_cores"] = all_cores
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

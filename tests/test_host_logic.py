@@ -90,3 +90,15 @@ def test_fused_kernel_lds_exchange_layouts():
     assert sim.check_exchange_routing()
     worst = sim.exchange_bank_conflicts()
     assert max(worst.values()) <= 2, worst
+
+
+def test_cpu_worker_of_the_all_cores_baseline_runs():
+    """bench.py's all-cores CPU leg starts oracle/cpu_worker.py once per core: it must run stand-alone
+    (no torch, no package import) and print the seconds it took."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "oracle", "cpu_worker.py"), "64", "16", "9", "3", "2", "1"],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert float(out.stdout.strip()) > 0.0

@@ -1583,6 +1583,148 @@ __global__ void __launch_bounds__(64 * kP2Waves, 1) k_gl1024_pair2(Pair2Args pp)
     }
 }
 
+// Low-latency form of the n_fft-1024 loop for problems too small to fill the GPU with runs of frames (config 1:
+// one utterance, 641 frames -> 160 runs of 4 frames, 24.5 us per iteration however few CUs are busy).  Here a
+// wave owns ONE pair of frames and nothing is carried from frame to frame: the state between iterations is not
+// the signal but the windowed inverse frames y[b][t][1024], and a wave rebuilds its two input frames from the
+// previous iteration's y as it loads them,
+//     x[nH + i] = sum over frames m (ascending, the order of the reference's += loop) of y[m][(n - m)H + i],
+// (up to ceil(N/H) terms per sample, all L2 hits), so every pair of an iteration runs at once and there are no
+// run seams, tails or rings.  The first iteration reads the start signal instead; k_ola1024 folds the last y
+// into the output signal.  Results do not depend on any work split.
+constexpr int kF1Waves = 4;
+constexpr int kF1MaxReach = 8;               // frames a sample can reach back/forward: floor((N-1)/H) <= 8, H >= 114
+struct Frames1024Args {
+    const float* x_in;      // [B][L] start signal (first iteration) or null
+    const float* y_in;      // [B][T][1024] windowed inverse frames of the previous iteration (x_in == null)
+    const float* mag;       // [B][T][513]
+    float* y_out;           // [B][T][1024]
+    const v2f* tab;
+    int H, T, B, reach;     // reach = (N-1)/H
+    long long L;
+};
+// REACH = floor((N-1)/H), a template parameter so that the gather is one straight block of (REACH+1) x 32 loads
+// per lane, all in flight together: y was written by CUs of other XCDs, so every dependent batch of loads costs
+// a trip to memory (about 2 us), and with a run-time loop there were REACH+1 of them in a row.
+template <int REACH>
+__global__ void __launch_bounds__(64 * kF1Waves) k_gl1024_frames(Frames1024Args p) {
+    __shared__ __attribute__((aligned(16))) v2f smem[16 * 64 + kF1Waves * kRScratch];
+    const int l = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i = threadIdx.x; i < 16 * 64; i += 64 * kF1Waves) smem[i] = p.tab[i];      // window entries 0..15
+    __syncthreads();
+    const int T = p.T, H = p.H;
+    const int npairs = (T + 1) >> 1;
+    const long long gp = (long long)blockIdx.x * kF1Waves + wave;
+    if (gp >= (long long)p.B * npairs) return;   // wave-uniform; no barrier after this point
+    const int b = (int)(gp / npairs);
+    const int n = 2 * (int)(gp - (long long)b * npairs);
+    const bool two = (n + 1 < T);
+    v2f* ex = smem + 16 * 64 + wave * kRScratch;
+    const v2f* tabl = smem + 2 * l;
+    v2f treg[kT2Twp - kT2Tw1];
+    {
+        const v2f* tg = p.tab + 2 * l;
+#pragma unroll
+        for (int e = kT2Tw1; e < kT2Twp; ++e) treg[e - kT2Tw1] = tg[TE(e)];
+    }
+    const TabMixed tb{tabl, treg};
+    const int a3 = l & 7, g3 = l >> 3;
+    const int kloB = l ? 128 - l : 64;
+    const bool l0 = (l == 0);
+
+    float ma[9], mb[9];
+    {
+        const float* ra = p.mag + ((long long)b * T + n) * (kN1 / 2 + 1);
+        const float* rb = ra + (two ? (kN1 / 2 + 1) : 0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = l ? (l + 128 * u) : (u < 4 ? 128 * u : 64 + 128 * (u - 4));
+            const int kk = k <= 512 ? k : 1024 - k;
+            ma[u] = ra[kk] * (1.0f / kM);                             // 1/M of the inverse transform (exact)
+            mb[u] = two ? rb[kk] * (1.0f / kM) : 0.0f;
+        }
+        ma[8] = ra[512] * (1.0f / kM);
+        mb[8] = two ? rb[512] * (1.0f / kM) : 0.0f;
+    }
+
+    v2f z[16];
+    if (p.x_in != nullptr) {
+        const float* xr = p.x_in + (long long)b * p.L + (long long)n * H;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            z[j].x = xr[l + 64 * j];
+            z[j].y = two ? xr[H + l + 64 * j] : 0.0f;
+        }
+    } else {
+        const float* yb = p.y_in + (long long)b * T * kN1;
+        // Sample i of frame a sits at s = nH + i of the signal; the frames covering s are m = m_hi - reach + c,
+        // c = 0..reach (ascending), m_hi = floor(s / H) = n + floor(i / H), at position s - mH, which is inside
+        // the frame when it is < N.  Frame b's sample i sits H further: same positions, frames one later.
+        // Every load is issued (clamped address) and masked afterwards, so the 32 of one c are in flight at once.
+        const float rh = 1.0f / (float)H;
+        const int last = T - 1;
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) z[jj] = (v2f){0.0f, 0.0f};
+#pragma unroll
+        for (int c = 0; c <= REACH; ++c) {
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) {
+                const int i = l + 64 * jj;
+                const int q = (int)(((float)i + 0.5f) * rh);          // floor(i / H), exact for i < 1024, H >= 114
+                const int dm = q - REACH + c;                         // m - n for frame a
+                const int pos = i - dm * H;                           // >= 0 by construction
+                const int m_a = n + dm, m_b = m_a + 1;
+                const bool in = pos < kN1;
+                const float va = yb[(long long)min(max(m_a, 0), last) * kN1 + min(pos, kN1 - 1)];
+                const float vb = yb[(long long)min(max(m_b, 0), last) * kN1 + min(pos, kN1 - 1)];
+                z[jj].x += (in && m_a >= 0 && m_a <= last) ? va : 0.0f;
+                z[jj].y += (two && in && m_b >= 0 && m_b <= last) ? vb : 0.0f;
+            }
+        }
+    }
+    bool a_nz = false, b_nz = false;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        a_nz |= (z[j].x != 0.0f);
+        b_nz |= (z[j].y != 0.0f);
+        z[j] = z[j] * tb.get(kT2Win + j);
+    }
+    // an all-zero input frame must give an exactly zero spectrum (see k_gl1024_pair)
+    const float ka = __any(a_nz) ? 1.0f : 0.0f;
+    const float kb = __any(b_nz) ? 1.0f : 0.0f;
+
+    Stamps st;
+    fft_forward_1024(z, ex, l, a3, g3, kloB, tb, st);
+    middle_two_frames(z, l0, ma, mb, ka, kb);
+    fft_inverse_1024(z, ex, l, a3, g3, kloB, tb, st);
+
+    float* ya = p.y_out + ((long long)b * T + n) * kN1;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const v2f w = tb.get(kT2Win + j);
+        ya[l + 64 * j] = z[j].x * w.x;
+        if (two) ya[kN1 + l + 64 * j] = z[j].y * w.y;
+    }
+}
+
+// x[b][s] = sum over frames m (ascending) of y[b][m][s - mH]: the overlap-add of audio_utilities.py:111-113 as a
+// gather; the last H samples no frame covers come out zero, like the reference's.
+__global__ void __launch_bounds__(256) k_ola1024(const float* __restrict__ y, float* __restrict__ x, long long L, int H,
+                                                 int T) {
+    const int b = blockIdx.y;
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= L) return;
+    const float* yb = y + (long long)b * T * kN1;
+    long long m_lo = (s - kN1 + H) / H;           // ceil((s - N + 1) / H) for s - N + 1 > 0
+    if (s - kN1 + 1 <= 0) m_lo = 0;
+    long long m_hi = s / H;
+    if (m_hi > T - 1) m_hi = T - 1;
+    float v = 0.0f;
+    for (long long m = m_lo; m <= m_hi; ++m) v += yb[m * kN1 + (s - m * H)];
+    x[(long long)b * L + s] = v;
+}
+
 // x_out[s] = x_main[s] + tail of the previous run (final fold after the last iteration)
 __global__ void __launch_bounds__(256) k_fold_tails(const float* __restrict__ x_main, const float* __restrict__ tail,
                                                     float* __restrict__ x_out, long long L, int g_h, int nruns,
@@ -1935,6 +2077,14 @@ int run_regring(gl_plan* p, const float* mag, const float* x0, float* x_out, int
 }
 
 
+// Frames (B*T) up to which the per-pair form is used.  Measured at T = 641, hop 275 (us per iteration, per-pair
+// form vs run kernels): B=1 13.5 / 24.5, B=4 19.3 / 25.4, B=8 24.9 / 36.8, B=16 42.7 / 51.1, B=24 55.0 / 61.9,
+// B=32 71.5 / 74.4 -- level at about 20 k frames; config 5 (32 x 1001) stays on the run kernels.
+static long long kF1MaxFrames(const gl_plan* p) {
+    static const char* e = getenv("GL_F1_MAX_FRAMES");   // experiments
+    return e ? atoll(e) : 64LL * p->n_cu;
+}
+
 int run_pair1024(gl_plan* p, const float* mag, const float* x0, float* x_out, int iters, int B, int T,
                  hipStream_t st) {
     int rc = ensure_table2(p);
@@ -1943,7 +2093,55 @@ int run_pair1024(gl_plan* p, const float* mag, const float* x0, float* x_out, in
     // small problems (config 1: one utterance) cannot fill 8 waves per CU and run faster on the first version,
     // whose LDS x ring hides the load latency a lone wave sees (measured 1.47 vs 1.70 ms for B=1, T=641);
     // from a few frames per wave slot on, the second version wins (config 5: 5.86 vs 8.37 ms)
-    static const char* force = getenv("GL_P1_VERSION");        // experiments: "1" or "2"
+    static const char* force = getenv("GL_P1_VERSION");        // experiments: "1", "2" or "f" (per-pair frames form)
+    const bool post = gl_post_needed(p);
+    // Too few frames to fill the GPU with runs: one wave per frame pair, state kept as frames (k_gl1024_frames).
+    // Not with a pinned run length (callers who pin it compare bits with the run kernels) nor with the optional
+    // per-iteration signal transforms, and only while a sample's reach stays small.
+    const int reach = (kN1 - 1) / p->hop;
+    const bool frames_ok = !post && p->run_frames == 0 && !getenv("GL_RUN_FRAMES") && reach >= 1 && reach <= kF1MaxReach && iters >= 1;
+    const bool frames_form = force ? (force[0] == 'f' && frames_ok) : (frames_ok && (long long)B * T <= kF1MaxFrames(p));
+    if (frames_form) {
+        const size_t need = (size_t)2 * B * T * kN1 * sizeof(float);
+        if (p->yframes_bytes < need) {
+            // grown on demand, never under stream capture: gl_fast_prepare sizes it for the plan's maximum
+            if (p->d_yframes) { GL_HIP_CHECK(hipStreamSynchronize(st)); GL_HIP_CHECK(hipFree(p->d_yframes)); p->bytes -= (long long)p->yframes_bytes; p->d_yframes = nullptr; p->yframes_bytes = 0; }
+            rc = gl_plan_alloc(p, (void**)&p->d_yframes, need);
+            if (rc) return rc;
+            p->yframes_bytes = need;
+        }
+        Frames1024Args f = {};
+        f.mag = mag;
+        f.tab = reinterpret_cast<const v2f*>(p->d_fast_tab2);
+        f.H = p->hop;
+        f.T = T;
+        f.B = B;
+        f.reach = reach;
+        f.L = gl_len(p->n_fft, p->hop, T);
+        float* ybuf[2] = {p->d_yframes, p->d_yframes + (size_t)B * T * kN1};
+        const long long pairs = (long long)B * ((T + 1) / 2);
+        for (int it = 0; it < iters; ++it) {
+            f.x_in = it == 0 ? x0 : nullptr;
+            f.y_in = it == 0 ? nullptr : ybuf[(it - 1) & 1];
+            f.y_out = ybuf[it & 1];
+            const dim3 grid((unsigned)((pairs + kF1Waves - 1) / kF1Waves)), block(64 * kF1Waves);
+            switch (reach) {
+                case 1: hipLaunchKernelGGL(k_gl1024_frames<1>, grid, block, 0, st, f); break;
+                case 2: hipLaunchKernelGGL(k_gl1024_frames<2>, grid, block, 0, st, f); break;
+                case 3: hipLaunchKernelGGL(k_gl1024_frames<3>, grid, block, 0, st, f); break;
+                case 4: hipLaunchKernelGGL(k_gl1024_frames<4>, grid, block, 0, st, f); break;
+                case 5: hipLaunchKernelGGL(k_gl1024_frames<5>, grid, block, 0, st, f); break;
+                case 6: hipLaunchKernelGGL(k_gl1024_frames<6>, grid, block, 0, st, f); break;
+                case 7: hipLaunchKernelGGL(k_gl1024_frames<7>, grid, block, 0, st, f); break;
+                default: hipLaunchKernelGGL(k_gl1024_frames<8>, grid, block, 0, st, f); break;
+            }
+            GL_HIP_CHECK(hipGetLastError());
+        }
+        hipLaunchKernelGGL(k_ola1024, dim3((unsigned)((f.L + 255) / 256), B), dim3(256), 0, st, ybuf[(iters - 1) & 1], x_out,
+                           f.L, p->hop, T);
+        GL_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     const bool v1 = force ? (force[0] == '1') : ((long long)B * T < 24LL * p->n_cu);
     const int waves = v1 ? kP1Waves : kP2Waves;
     const int G = pick_run_length(p, B, T, waves);
@@ -1960,7 +2158,6 @@ int run_pair1024(gl_plan* p, const float* mag, const float* x0, float* x_out, in
     a.L = gl_len(p->n_fft, p->hop, T);
     const float* src = x0;
     const float* src_tail = nullptr;
-    const bool post = gl_post_needed(p);
     for (int it = 0; it < iters; ++it) {
         const bool last = (it == iters - 1);
         float* dst = (it & 1) ? p->d_xb : p->d_xa;
@@ -2015,7 +2212,18 @@ bool gl_fast_supported(const gl_plan* p, int op) {
 int gl_fast_prepare(gl_plan* p) {
     int rc = ensure_buffers(p);
     if (rc) return rc;
-    if (p->n_fft == kN1) return ensure_table2(p);
+    if (p->n_fft == kN1) {
+        rc = ensure_table2(p);
+        long long fr = (long long)p->max_B * p->max_T;
+        if (fr > kF1MaxFrames(p)) fr = kF1MaxFrames(p);
+        const size_t need = (size_t)2 * fr * kN1 * sizeof(float);          // per-pair form of small problems
+        if (!rc && p->yframes_bytes < need) {
+            if (p->d_yframes) { GL_HIP_CHECK(hipFree(p->d_yframes)); p->bytes -= (long long)p->yframes_bytes; p->d_yframes = nullptr; p->yframes_bytes = 0; }
+            rc = gl_plan_alloc(p, (void**)&p->d_yframes, need);
+            if (!rc) p->yframes_bytes = need;
+        }
+        return rc;
+    }
     rc = ensure_table(p);
     if (!rc && p->hop % 128 == 0) {
         rc = ensure_table2(p);

@@ -32,6 +32,8 @@ struct gl_plan {
     int wsum_T;
     float* d_prev;      // [max_B][L] previous iterate for the momentum option (lazy)
     float* d_window_p;  // [N] periodic Hann of the analysis path (lazy)
+    float* d_yframes;   // n_fft 1024, small problems: two sets of windowed inverse frames [2][B][T][N] (lazy)
+    size_t yframes_bytes;
     long long bytes;
 };
 

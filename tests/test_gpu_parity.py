@@ -614,7 +614,7 @@ def test_ragged_batch_equals_per_utterance_runs(N, H, path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("version", ["1", "2"])
+@pytest.mark.parametrize("version", ["1", "2", "f"])
 def test_n1024_both_kernel_versions_on_small_cases(version):
     """gl_run picks the n_fft-1024 kernel version by problem size; force each one (GL_P1_VERSION is read once
     per process, hence the subprocess) over small cases with tails, odd frame counts and a zero frame."""

@@ -13,7 +13,8 @@
 //   k_fast2048<MODE>     n_fft 2048, any hop; rings in LDS; also the single-shot STFT / ISTFT
 //   k_gl2048_regring<HS> n_fft 2048, hop 128*HS: rings in registers, two frames in flight per wave
 //                        (the benchmark kernel)
-//   k_gl1024_pair / k_gl1024_pair2   n_fft 1024, any hop: two real frames per complex FFT
+//   k_gl1024_pair / k_gl1024_pair2   n_fft 1024, any hop: two real frames per complex FFT, runs of frames per wave
+//   k_gl1024_frames<REACH> + k_ola1024   n_fft 1024, small problems: one frame pair per wave, state kept as frames
 //   k_analysis2048       n_fft 2048: |centred STFT| of the forward analysis path (wav -> log-mel), one wave per frame
 // The FFT core (dft16/dft8, twiddle1/2, ex1_*/ex2_* transposes, middle_project) is shared.
 //
@@ -1465,21 +1466,12 @@ __global__ void __launch_bounds__(64 * kP2Waves, 1) k_gl1024_pair2(Pair2Args pp)
     const int kloB = l ? 128 - l : 64;
     const bool l0 = (l == 0);
     const float* xr = p.x_in + (long long)b * p.L;
-    // tails (partial sums the producer of x_in left aside): the previous run's cover the first N-H samples of
-    // this run's region, this run's own the first N-H samples of the next run's region
-    const bool has_tail = (p.tail_in != nullptr);
-    const float* t_prev = (has_tail && run >= 1) ? p.tail_in + ((long long)b * p.nruns + run - 1) * ovl : nullptr;
-    const float* t_own = (has_tail && run + 1 < p.nruns) ? p.tail_in + ((long long)b * p.nruns + run) * ovl : nullptr;
-    const long long s_lo = (long long)f0 * H;                 // first sample of this run's region
-    const long long s_hi = (long long)(f0 + p.G) * H;         // first sample of the next run's region
-    auto sample = [&](long long s, bool tails) -> float {
-        float v = xr[s];
-        if (tails) {
-            const long long dp = s - s_lo, dn = s - s_hi;
-            if (t_prev != nullptr && dp < ovl) v += t_prev[dp];
-            if (t_own != nullptr && dn >= 0 && dn < ovl) v += t_own[dn];
-        }
-        return v;
+    // x_in is complete: the host folds the run tails of the previous iteration into it (k_fold_seams) before this
+    // launch.  (Folding them here, as the first version did, put 96 loads with per-lane conditions in front of
+    // every pair at a run seam -- half of all pairs at config 5 -- which the compiler issued three at a time
+    // between full waits: 32 trips to memory in a row per pair.)
+    auto ldb = [](__amdgpu_buffer_rsrc_t rs, int byte_off) -> float {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, byte_off, 0, 0));
     };
 
 #pragma unroll
@@ -1493,43 +1485,46 @@ __global__ void __launch_bounds__(64 * kP2Waves, 1) k_gl1024_pair2(Pair2Args pp)
     }
     kk[8] = 512;
 
+    // Operands of pair n (raw samples of both frames, magnitudes): requested one pair ahead, so their round trip
+    // to memory runs under the transforms of the pair before.
+    auto fetch = [&](int n, v2f (&xz)[16], float (&fa)[9], float (&fb)[9]) {
+        const bool two = (n + 1 < f1);
+        const long long sn = (long long)n * H;
+        const float* ra = p.mag + ((long long)b * T + n) * (kN1 / 2 + 1);
+        const float* rb = ra + (two ? (kN1 / 2 + 1) : 0);
+#pragma unroll
+        for (int u = 0; u < 9; ++u) { fa[u] = ra[kk[u]]; fb[u] = rb[kk[u]]; }
+        const long long sb = two ? sn + H : sn;                       // a lone last frame: b re-reads a (discarded)
+        // buffer loads: wave-uniform base in scalar registers + one 32-bit lane offset for all 32
+        const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)(xr + sn), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)(xr + sb), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { xz[j].x = ldb(rs_a, 4 * (l + 64 * j)); xz[j].y = ldb(rs_b, 4 * (l + 64 * j)); }
+    };
+    v2f xn[16];
+    float fa[9], fb[9];
+    if (f0 < f1) fetch(f0, xn, fa, fb);
+
     for (int n = f0; n < f1; n += 2) {
         const bool two = (n + 1 < f1);
         const long long sn = (long long)n * H;
-        // wave-uniform: does this pair read any sample that has a tail?
-        const bool tails = has_tail && ((t_prev != nullptr && sn < s_lo + ovl) || (t_own != nullptr && sn + kN1 + H > s_hi));
-
         float ma[9], mb[9];
-        {
-            const float* ra = p.mag + ((long long)b * T + n) * (kN1 / 2 + 1);
-            const float* rb = ra + (two ? (kN1 / 2 + 1) : 0);
-#pragma unroll
-            for (int u = 0; u < 9; ++u) {
-                ma[u] = ra[kk[u]] * (1.0f / kM);                      // 1/M of the inverse transform (exact)
-                mb[u] = two ? rb[kk[u]] * (1.0f / kM) : 0.0f;
-            }
-        }
         v2f z[16];
-        bool a_nz = false, b_nz = false;
-        if (tails) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                z[j].x = sample(sn + l + 64 * j, true);
-                z[j].y = two ? sample(sn + H + l + 64 * j, true) : 0.0f;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                z[j].x = xr[sn + l + 64 * j];
-                z[j].y = two ? xr[sn + H + l + 64 * j] : 0.0f;
-            }
+        for (int u = 0; u < 9; ++u) {
+            ma[u] = fa[u] * (1.0f / kM);                              // 1/M of the inverse transform (exact)
+            mb[u] = two ? fb[u] * (1.0f / kM) : 0.0f;
         }
+        bool a_nz = false, b_nz = false;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
+            z[j].x = xn[j].x;
+            z[j].y = two ? xn[j].y : 0.0f;
             a_nz |= (z[j].x != 0.0f);
             b_nz |= (z[j].y != 0.0f);
             z[j] = z[j] * tb.get(kT2Win + j);
         }
+        if (n + 2 < f1) fetch(n + 2, xn, fa, fb);                     // wave-uniform
         // an all-zero input frame must give an exactly zero spectrum (phase 0 after projection,
         // audio_utilities.py:181): its partner's rounding noise must not set its phase
         const float ka = __any(a_nz) ? 1.0f : 0.0f;
@@ -1723,6 +1718,20 @@ __global__ void __launch_bounds__(256) k_ola1024(const float* __restrict__ y, fl
     float v = 0.0f;
     for (long long m = m_lo; m <= m_hi; ++m) v += yb[m * kN1 + (s - m * H)];
     x[(long long)b * L + s] = v;
+}
+
+// x[b][run*G*H + i] += tail[b][run-1][i], i < N-H, run = 1..nruns-1, in place: completes the signal between two
+// iterations of the n_fft-1024 run kernels (one add per sample, the same "main + tail" the consumer used to do).
+__global__ void __launch_bounds__(256) k_fold_seams(float* __restrict__ x, const float* __restrict__ tail, long long L,
+                                                    int g_h, int nruns, int ovl, int blocks_per_seam) {
+    const long long seam = blockIdx.x / blocks_per_seam;             // (b, run - 1), flattened
+    const int i = (int)(blockIdx.x - seam * blocks_per_seam) * 256 + threadIdx.x;
+    const int b = (int)(seam / (nruns - 1));
+    const int run = (int)(seam - (long long)b * (nruns - 1)) + 1;
+    if (i >= ovl) return;
+    const long long s = (long long)run * g_h + i;
+    if (s >= L) return;
+    x[(long long)b * L + s] += tail[((long long)b * nruns + run - 1) * ovl + i];
 }
 
 // x_out[s] = x_main[s] + tail of the previous run (final fold after the last iteration)
@@ -2078,11 +2087,11 @@ int run_regring(gl_plan* p, const float* mag, const float* x0, float* x_out, int
 
 
 // Frames (B*T) up to which the per-pair form is used.  Measured at T = 641, hop 275 (us per iteration, per-pair
-// form vs run kernels): B=1 13.5 / 24.5, B=4 19.3 / 25.4, B=8 24.9 / 36.8, B=16 42.7 / 51.1, B=24 55.0 / 61.9,
-// B=32 71.5 / 74.4 -- level at about 20 k frames; config 5 (32 x 1001) stays on the run kernels.
+// form vs the run kernel k_gl1024_pair2): B=1 13.5 / 20.0, B=4 19.3 / 23.8, B=6 20.6 / 25.2, B=8 24.9 / 25.4,
+// B=12 33.4 / 27.8, B=16 42.7 / 33.6: level at about 5 000 frames.
 static long long kF1MaxFrames(const gl_plan* p) {
     static const char* e = getenv("GL_F1_MAX_FRAMES");   // experiments
-    return e ? atoll(e) : 64LL * p->n_cu;
+    return e ? atoll(e) : 20LL * p->n_cu;
 }
 
 int run_pair1024(gl_plan* p, const float* mag, const float* x0, float* x_out, int iters, int B, int T,
@@ -2090,9 +2099,10 @@ int run_pair1024(gl_plan* p, const float* mag, const float* x0, float* x_out, in
     int rc = ensure_table2(p);
     if (!rc) rc = ensure_buffers(p);
     if (rc) return rc;
-    // small problems (config 1: one utterance) cannot fill 8 waves per CU and run faster on the first version,
-    // whose LDS x ring hides the load latency a lone wave sees (measured 1.47 vs 1.70 ms for B=1, T=641);
-    // from a few frames per wave slot on, the second version wins (config 5: 5.86 vs 8.37 ms)
+    // Three forms: the per-pair frames form for small problems (below), k_gl1024_pair2 for everything else, and the
+    // first run kernel k_gl1024_pair (4 waves per CU, x ring in LDS), which nothing selects any more since the run
+    // tails are folded between iterations (B=1, T=641: 24.9 us per iteration vs 20.0 for pair2 and 13.5 per-pair);
+    // it stays as an independent implementation the tests force with GL_P1_VERSION=1.
     static const char* force = getenv("GL_P1_VERSION");        // experiments: "1", "2" or "f" (per-pair frames form)
     const bool post = gl_post_needed(p);
     // Too few frames to fill the GPU with runs: one wave per frame pair, state kept as frames (k_gl1024_frames).
@@ -2142,7 +2152,7 @@ int run_pair1024(gl_plan* p, const float* mag, const float* x0, float* x_out, in
         GL_HIP_CHECK(hipGetLastError());
         return 0;
     }
-    const bool v1 = force ? (force[0] == '1') : ((long long)B * T < 24LL * p->n_cu);
+    const bool v1 = force && force[0] == '1';
     const int waves = v1 ? kP1Waves : kP2Waves;
     const int G = pick_run_length(p, B, T, waves);
     const int nruns = (T + G - 1) / G;
@@ -2180,6 +2190,16 @@ int run_pair1024(gl_plan* p, const float* mag, const float* x0, float* x_out, in
             rc = gl_post_iter(p, dst, src_tail, o, B, T, G, nruns, it == 0, last, st);
             if (rc) return rc;
             src = o;
+            src_tail = nullptr;
+        } else if (!last && nruns > 1) {
+            // complete the signal in place: the kernels read x_in without tails
+            const int ovl = p->n_fft - p->hop;
+            const int bps = (ovl + 255) / 256;
+            if (ovl > 0) {                                            // hop == n_fft: frames do not overlap, no tails
+                hipLaunchKernelGGL(k_fold_seams, dim3((unsigned)((long long)bps * (nruns - 1) * B)), dim3(256), 0, st,
+                                   dst, dst_tail, a.L, G * p->hop, nruns, ovl, bps);
+                GL_HIP_CHECK(hipGetLastError());
+            }
             src_tail = nullptr;
         }
     }

@@ -475,7 +475,7 @@ __global__ void __launch_bounds__(64) k_fast2048(FastArgs p) {
 // frames in flight per wave (GL_PIPE, see the loop).
 // =====================================================================================
 #ifndef GL_ABL
-#define GL_ABL 0   // timing experiments only: 1 skip LDS transposes, 2 skip projection step, 4 constant twiddles
+#define GL_ABL 0   // timing experiments only: 1 skip LDS transposes, 2 skip projection step, 4 constant twiddles, 16 skip the overlap-add of k_gl1024_pair2
 #endif
 #ifndef GL_SETPRIO
 #define GL_SETPRIO 0   // experiment: raise the wave's issue priority while it feeds the LDS queue
@@ -1532,11 +1532,11 @@ __global__ void __launch_bounds__(64 * kP2Waves, 1) k_gl1024_pair2(Pair2Args pp)
 
         Stamps st;
         fft_forward_1024(z, ex, l, a3, g3, kloB, tb, st);
-        middle_two_frames(z, l0, ma, mb, ka, kb);
+        if (!(GL_ABL & 2)) middle_two_frames(z, l0, ma, mb, ka, kb);
         fft_inverse_1024(z, ex, l, a3, g3, kloB, tb, st);
 
         // window, overlap-add: frame a then frame b (frame order, like the reference)
-        {
+        if (!(GL_ABL & 16)) {
             const int base_a = (int)(sn & (kP1Ring - 1));
             const int base_b = (int)((sn + H) & (kP1Ring - 1));
             __builtin_amdgcn_wave_barrier();

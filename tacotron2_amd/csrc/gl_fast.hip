@@ -1535,32 +1535,35 @@ __global__ void __launch_bounds__(64 * kP2Waves, 1) k_gl1024_pair2(Pair2Args pp)
         if (!(GL_ABL & 2)) middle_two_frames(z, l0, ma, mb, ka, kb);
         fft_inverse_1024(z, ex, l, a3, g3, kloB, tb, st);
 
-        // window, overlap-add: frame a then frame b (frame order, like the reference)
+        // window, overlap-add: frame a then frame b (frame order, like the reference).  A sample is complete once
+        // the last frame covering it has been added: the first H samples of frame a after a (frame b starts H
+        // later), the first H of frame b after b (the next pair starts 2H later).  Those leave for global memory
+        // straight from the add and their ring slots are cleared in the same pass -- no separate emit loop.
         if (!(GL_ABL & 16)) {
             const int base_a = (int)(sn & (kP1Ring - 1));
             const int base_b = (int)((sn + H) & (kP1Ring - 1));
+            float* orow = p.x_out + (long long)b * p.L + sn + l;
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                v2f w = tb.get(kT2Win + j);
-                acc[(base_a + l + 64 * j) & (kP1Ring - 1)] += z[j].x * w.x;
+                const v2f w = tb.get(kT2Win + j);
+                const int q = (base_a + l + 64 * j) & (kP1Ring - 1);
+                const float v = acc[q] + z[j].x * w.x;
+                const bool fin = l + 64 * j < H;
+                acc[q] = fin ? 0.0f : v;
+                if (fin) orow[64 * j] = v;
             }
             __builtin_amdgcn_wave_barrier();
             if (two) {
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
-                    v2f w = tb.get(kT2Win + j);
-                    acc[(base_b + l + 64 * j) & (kP1Ring - 1)] += z[j].y * w.y;
+                    const v2f w = tb.get(kT2Win + j);
+                    const int q = (base_b + l + 64 * j) & (kP1Ring - 1);
+                    const float v = acc[q] + z[j].y * w.y;
+                    const bool fin = l + 64 * j < H;
+                    acc[q] = fin ? 0.0f : v;
+                    if (fin) orow[H + 64 * j] = v;
                 }
-            }
-            __builtin_amdgcn_wave_barrier();
-            // samples [sn, sn + H) (or 2H) are complete: emit once and clear
-            const int done = two ? 2 * H : H;
-            float* orow = p.x_out + (long long)b * p.L;
-            for (int i = l; i < done; i += 64) {
-                int q = (int)((sn + i) & (kP1Ring - 1));
-                orow[sn + i] = acc[q];
-                acc[q] = 0.0f;
             }
             __builtin_amdgcn_wave_barrier();
         }

@@ -1457,6 +1457,14 @@ __global__ void __launch_bounds__(64 * kP2Waves, 1) k_gl1024_pair2(Pair2Args pp)
         for (int e = kT2Tw1; e < kT2Twp; ++e) treg[e - kT2Tw1] = tg[TE(e)];
     }
     const TabMixed tb{tabl, treg};
+    // both frames of a pair see the same window value, so the 16 per lane are 16 scalars: kept in registers
+    // (48 LDS reads per pair otherwise)
+    float wreg[16];
+    {
+        const v2f* tg = p.tab + 2 * l;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) wreg[j] = tg[TE(kT2Win + j)].x;
+    }
 
     const int H = p.H, T = p.T;
     const int f0 = run * p.G;
@@ -1522,7 +1530,7 @@ __global__ void __launch_bounds__(64 * kP2Waves, 1) k_gl1024_pair2(Pair2Args pp)
             z[j].y = two ? xn[j].y : 0.0f;
             a_nz |= (z[j].x != 0.0f);
             b_nz |= (z[j].y != 0.0f);
-            z[j] = z[j] * tb.get(kT2Win + j);
+            z[j] = z[j] * wreg[j];
         }
         if (n + 2 < f1) fetch(n + 2, xn, fa, fb);                     // wave-uniform
         // an all-zero input frame must give an exactly zero spectrum (phase 0 after projection,
@@ -1546,9 +1554,8 @@ __global__ void __launch_bounds__(64 * kP2Waves, 1) k_gl1024_pair2(Pair2Args pp)
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const v2f w = tb.get(kT2Win + j);
                 const int q = (base_a + l + 64 * j) & (kP1Ring - 1);
-                const float v = acc[q] + z[j].x * w.x;
+                const float v = acc[q] + z[j].x * wreg[j];
                 const bool fin = l + 64 * j < H;
                 acc[q] = fin ? 0.0f : v;
                 if (fin) orow[64 * j] = v;
@@ -1557,9 +1564,8 @@ __global__ void __launch_bounds__(64 * kP2Waves, 1) k_gl1024_pair2(Pair2Args pp)
             if (two) {
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
-                    const v2f w = tb.get(kT2Win + j);
                     const int q = (base_b + l + 64 * j) & (kP1Ring - 1);
-                    const float v = acc[q] + z[j].y * w.y;
+                    const float v = acc[q] + z[j].y * wreg[j];
                     const bool fin = l + 64 * j < H;
                     acc[q] = fin ? 0.0f : v;
                     if (fin) orow[H + 64 * j] = v;

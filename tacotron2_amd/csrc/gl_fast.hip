@@ -1262,42 +1262,39 @@ struct Pair1024Args {
     long long L;
 };
 
-// projection step for two frames sharing one complex spectrum (see header above)
+// projection step for two frames sharing one complex spectrum (see header above), in packed form:
+//   S = P + conj Q = 2 Xa,  D = P - conj Q = 2i Xb;  Ya = project(S, ma),  Yb = i project(-i D, mb) = project'(D, mb)
+//   where project' nudges the IMAGINARY part, so that a zero bin of frame b becomes i (mb, 0) as before;
+//   P' = Ya + Yb,  Q' = conj(Ya - Yb).  ka / kb = 0 force the spectrum of an all-zero frame to exactly zero.
+// Lane 0's self-mirrored pairs are rotated into place by two masked move chains (see middle_project).
+__device__ __forceinline__ v2f project_im(v2f X, float m) {
+    const v2f Xe = X + (v2f){0.0f, 0x1p-60f};
+    const float r2 = fmaxf(fmaf(Xe.x, Xe.x, Xe.y * Xe.y), 0x1p-124f);
+    const float sc = m * __builtin_amdgcn_rsqf(r2);
+    return Xe * (v2f){sc, sc};
+}
 __device__ __forceinline__ void middle_two_frames(v2f* z, bool l0, const float* ma, const float* mb, float ka,
                                                   float kb) {
     v2f P[9], Q[9];
-    P[0] = z[0];
-    Q[0] = sel(l0, z[0], z[15]);
+    const v2f z4 = z[4];
+    lane0_chain(z[4], z[8], z[12], z[5], z[9], z[13], z[6], z[10], z[14], z[7], z[11], z[15], z[0]);
 #pragma unroll
-    for (int c = 1; c < 4; ++c) { P[c] = z[c]; Q[c] = sel(l0, z[8 - c], z[15 - c]); }
-#pragma unroll
-    for (int c = 4; c < 8; ++c) { P[c] = sel(l0, z[8 + c - 4], z[c]); Q[c] = sel(l0, z[8 + 11 - c], z[15 - c]); }
-    P[8] = z[4];
-    Q[8] = z[4];
+    for (int c = 0; c < 8; ++c) { P[c] = z[c]; Q[c] = z[15 - c]; }
+    P[8] = z4;
+    Q[8] = z4;
 #pragma unroll
     for (int u = 0; u < 9; ++u) {
-        v2f S, D;
-        S.x = (P[u].x + Q[u].x) * ka;  S.y = (P[u].y - Q[u].y) * ka;     // P + conj(Q), forced to 0 for an all-zero frame a
-        D.x = (P[u].x - Q[u].x) * kb;  D.y = (P[u].y + Q[u].y) * kb;     // P - conj(Q)
-        float2 ya = gl_project(make_float2(S.x, S.y), ma[u]);            // Xa' (zero bin -> (ma, 0))
-        float2 xb = gl_project(make_float2(D.y, -D.x), mb[u]);           // Xb' from Xb = -i*D/2
-        v2f Ya = {ya.x, ya.y};
-        v2f Yb = {-xb.y, xb.x};                                          // i*Xb'
+        const v2f S = pk_addc(P[u], Q[u]) * ka;
+        const v2f D = pk_subc(P[u], Q[u]) * kb;
+        const v2f Ya = project(S, ma[u]);
+        const v2f Yb = project_im(D, mb[u]);
         P[u] = Ya + Yb;
-        v2f t = Ya - Yb;
-        Q[u].x = t.x;
-        Q[u].y = -t.y;
+        Q[u] = pk_subcc(Ya, Yb);
     }
-    z[0] = P[0];
+    lane0_chain(Q[0], Q[4], P[7], Q[1], Q[5], P[6], Q[2], Q[6], P[5], Q[3], Q[7], P[4], P[8]);
 #pragma unroll
-    for (int c = 1; c < 4; ++c) z[c] = P[c];
-    z[4] = sel(l0, P[8], P[4]);
-#pragma unroll
-    for (int c = 5; c < 8; ++c) z[c] = sel(l0, Q[8 - c], P[c]);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) z[8 + i] = sel(l0, P[4 + i], Q[7 - i]);
-#pragma unroll
-    for (int i = 4; i < 8; ++i) z[8 + i] = sel(l0, Q[11 - i], Q[7 - i]);
+    for (int c = 0; c < 8; ++c) { z[c] = P[c]; z[8 + c] = Q[7 - c]; }
+    (void)l0;
 }
 
 __global__ void __launch_bounds__(64 * kP1Waves, 1) k_gl1024_pair(Pair1024Args p) {

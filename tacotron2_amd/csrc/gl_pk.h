@@ -28,6 +28,7 @@ GL_PK2(pk_addi, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,
 GL_PK2(pk_subi, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]")   // a - i*b
 GL_PK2(pk_addc, "v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]")                                // a + conj(b)
 GL_PK2(pk_subc, "v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]")                                // a - conj(b)
+GL_PK2(pk_subcc, "v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[1,0]")                   // conj(a - b)
 GL_PK2(pk_swapc_add, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[1,0]")  // conj(a) + (b.y, b.x)
 
 // halves of a complex multiply: (a.x * w) and (a.y * i*w) [+ c]

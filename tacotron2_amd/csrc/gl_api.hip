@@ -152,7 +152,7 @@ int gl_plan_destroy(gl_plan* p) {
     DeviceGuard guard(p->device);
     void* ptrs[] = {p->d_window, p->d_tw,     p->d_frames, p->d_xa,      p->d_xb,
                     p->d_tail_a, p->d_tail_b, p->d_fast_tab, p->d_peaks, p->d_fast_tab2, p->d_magp,
-                    p->d_inv_wsum, p->d_prev, p->d_window_p, p->d_yframes};
+                    p->d_inv_wsum, p->d_prev, p->d_window_p, p->d_yframes, p->d_xc};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     delete p;

@@ -1432,6 +1432,7 @@ constexpr int kP2WaveLds = kRScratch + kP1Ring / 2;      // v2f units: transpose
 struct Pair2Args {
     Pair1024Args a;
     int B;
+    float* x_zero;          // [B][L] the buffer the next launch writes: its seam regions are cleared here (or null)
 };
 __global__ void __launch_bounds__(64 * kP2Waves, 1) k_gl1024_pair2(Pair2Args pp) {
     const Pair1024Args& p = pp.a;
@@ -1471,10 +1472,25 @@ __global__ void __launch_bounds__(64 * kP2Waves, 1) k_gl1024_pair2(Pair2Args pp)
     const int kloB = l ? 128 - l : 64;
     const bool l0 = (l == 0);
     const float* xr = p.x_in + (long long)b * p.L;
-    // x_in is complete: the host folds the run tails of the previous iteration into it (k_fold_seams) before this
-    // launch.  (Folding them here, as the first version did, put 96 loads with per-lane conditions in front of
-    // every pair at a run seam -- half of all pairs at config 5 -- which the compiler issued three at a time
-    // between full waits: 32 trips to memory in a row per pair.)
+    // x_in is complete.  Run seams: the N-H samples after a run's last frame belong to the next run's region; both
+    // runs ADD their partial sums there with hardware float atomics onto zeros (two terms onto 0: the result does
+    // not depend on which arrives first), and every launch clears the seam regions of the buffer the NEXT launch
+    // will write (x_zero; three signal buffers rotate).  Earlier forms: tails folded by the consumer (96 loads
+    // with per-lane conditions in front of every pair at a seam, issued three at a time between full waits -- 32
+    // trips to memory in a row, half of all pairs at config 5), then folded by a separate in-place kernel between
+    // iterations (5.9 us of launch per iteration for 1.5 M samples).
+    const long long s_lo = (long long)f0 * H;                 // first sample of this run's region
+    float* xo = p.x_out + (long long)b * p.L;
+    const bool seamed = run >= 1 && ovl > 0;                  // [s_lo, s_lo + ovl) also receives the previous run's sums
+    auto put = [&](long long s, float v, bool on) {           // sample s of the output is complete (for this run)
+        if (!on) return;
+        if (seamed && s < s_lo + ovl) unsafeAtomicAdd(xo + s, v);
+        else xo[s] = v;
+    };
+    if (pp.x_zero != nullptr && seamed) {
+        float* zr = pp.x_zero + (long long)b * p.L + s_lo;
+        for (int i = l; i < ovl; i += 64) zr[i] = 0.0f;
+    }
     auto ldb = [](__amdgpu_buffer_rsrc_t rs, int byte_off) -> float {
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, byte_off, 0, 0));
     };
@@ -1547,7 +1563,6 @@ __global__ void __launch_bounds__(64 * kP2Waves, 1) k_gl1024_pair2(Pair2Args pp)
         if (!(GL_ABL & 16)) {
             const int base_a = (int)(sn & (kP1Ring - 1));
             const int base_b = (int)((sn + H) & (kP1Ring - 1));
-            float* orow = p.x_out + (long long)b * p.L + sn + l;
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
@@ -1555,7 +1570,7 @@ __global__ void __launch_bounds__(64 * kP2Waves, 1) k_gl1024_pair2(Pair2Args pp)
                 const float v = acc[q] + z[j].x * wreg[j];
                 const bool fin = l + 64 * j < H;
                 acc[q] = fin ? 0.0f : v;
-                if (fin) orow[64 * j] = v;
+                put(sn + l + 64 * j, v, fin);
             }
             __builtin_amdgcn_wave_barrier();
             if (two) {
@@ -1565,22 +1580,20 @@ __global__ void __launch_bounds__(64 * kP2Waves, 1) k_gl1024_pair2(Pair2Args pp)
                     const float v = acc[q] + z[j].y * wreg[j];
                     const bool fin = l + 64 * j < H;
                     acc[q] = fin ? 0.0f : v;
-                    if (fin) orow[H + 64 * j] = v;
+                    put(sn + H + l + 64 * j, v, fin);
                 }
             }
             __builtin_amdgcn_wave_barrier();
         }
     }
 
-    // partial sums of the N-H samples after the run's last frame
+    // partial sums of the N-H samples after the run's last frame: the end of the signal, or the next run's seam
     const long long se = (long long)f1 * H;
     if (f1 == T) {
-        float* orow = p.x_out + (long long)b * p.L;
-        for (int i = l; i < ovl; i += 64) orow[se + i] = acc[(int)((se + i) & (kP1Ring - 1))];
-        for (int i = l; i < H; i += 64) orow[se + ovl + i] = 0.0f;
+        for (int i = l; i < ovl; i += 64) put(se + i, acc[(int)((se + i) & (kP1Ring - 1))], true);
+        for (int i = l; i < H; i += 64) xo[se + ovl + i] = 0.0f;
     } else {
-        float* trow = p.tail_out + ((long long)b * p.nruns + run) * ovl;
-        for (int i = l; i < ovl; i += 64) trow[i] = acc[(int)((se + i) & (kP1Ring - 1))];
+        for (int i = l; i < ovl; i += 64) unsafeAtomicAdd(xo + se + i, acc[(int)((se + i) & (kP1Ring - 1))]);
     }
 }
 
@@ -2179,6 +2192,37 @@ int run_pair1024(gl_plan* p, const float* mag, const float* x0, float* x_out, in
     a.G = G;
     a.nruns = nruns;
     a.L = gl_len(p->n_fft, p->hop, T);
+    if (!v1) {
+        // k_gl1024_pair2: seams by atomics onto cleared regions; three signal buffers rotate (read, write, clear)
+        if (!p->d_xc) {
+            rc = gl_plan_alloc(p, (void**)&p->d_xc, (size_t)p->max_B * gl_len(p->n_fft, p->hop, p->max_T) * sizeof(float));
+            if (rc) return rc;
+        }
+        float* buf[3] = {p->d_xa, p->d_xb, p->d_xc};
+        const size_t bytes = (size_t)B * a.L * sizeof(float);
+        if (nruns > 1) GL_HIP_CHECK(hipMemsetAsync(buf[0], 0, bytes, st));     // seams of the first target
+        const float* src = x0;
+        for (int it = 0; it < iters; ++it) {
+            const bool last = (it == iters - 1);
+            float* dst = buf[it % 3];
+            a.x_in = src;
+            a.x_out = dst;
+            aa.x_zero = (nruns > 1 && !last) ? buf[(it + 1) % 3] : nullptr;
+            hipLaunchKernelGGL(k_gl1024_pair2, dim3((unsigned)(((long long)nruns * B + kP2Waves - 1) / kP2Waves)),
+                               dim3(64 * kP2Waves), 0, st, aa);
+            GL_HIP_CHECK(hipGetLastError());
+            src = dst;
+            if (post) {      // optional variants: the signal is complete; transform it (in place, or into x_out)
+                float* o = last ? x_out : dst;
+                rc = gl_post_iter(p, dst, nullptr, o, B, T, G, nruns, it == 0, last, st);
+                if (rc) return rc;
+                src = o;
+            }
+        }
+        if (!post) GL_HIP_CHECK(hipMemcpyAsync(x_out, src, bytes, hipMemcpyDeviceToDevice, st));
+        return 0;
+    }
+    // first version (forced by the tests): tails in a side buffer, folded in place between iterations
     const float* src = x0;
     const float* src_tail = nullptr;
     for (int it = 0; it < iters; ++it) {
@@ -2190,11 +2234,7 @@ int run_pair1024(gl_plan* p, const float* mag, const float* x0, float* x_out, in
         a.tail_in = src_tail;
         a.x_out = dst;
         a.tail_out = dst_tail;
-        if (v1)
-            hipLaunchKernelGGL(k_gl1024_pair, dim3((nruns + kP1Waves - 1) / kP1Waves, B), dim3(64 * kP1Waves), 0, st, a);
-        else
-            hipLaunchKernelGGL(k_gl1024_pair2, dim3((unsigned)(((long long)nruns * B + kP2Waves - 1) / kP2Waves)),
-                               dim3(64 * kP2Waves), 0, st, aa);
+        hipLaunchKernelGGL(k_gl1024_pair, dim3((nruns + kP1Waves - 1) / kP1Waves, B), dim3(64 * kP1Waves), 0, st, a);
         GL_HIP_CHECK(hipGetLastError());
         src = dst;
         src_tail = (nruns > 1) ? dst_tail : nullptr;
@@ -2247,6 +2287,8 @@ int gl_fast_prepare(gl_plan* p) {
     if (rc) return rc;
     if (p->n_fft == kN1) {
         rc = ensure_table2(p);
+        if (!rc && !p->d_xc)
+            rc = gl_plan_alloc(p, (void**)&p->d_xc, (size_t)p->max_B * gl_len(p->n_fft, p->hop, p->max_T) * sizeof(float));
         long long fr = (long long)p->max_B * p->max_T;
         if (fr > kF1MaxFrames(p)) fr = kF1MaxFrames(p);
         const size_t need = (size_t)2 * fr * kN1 * sizeof(float);          // per-pair form of small problems

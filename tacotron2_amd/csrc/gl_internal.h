@@ -20,6 +20,7 @@ struct gl_plan {
     float* d_frames;  // generic path scratch [max_B][max_T][N] (lazy)
     float* d_xa;      // ping-pong signal buffers [max_B][L] (lazy)
     float* d_xb;
+    float* d_xc;      // third signal buffer of the n_fft-1024 run kernel (read / write / clear rotation; lazy)
     float* d_tail_a;  // fused path: per-run partial-sum tails (lazy)
     float* d_tail_b;
     float* d_fast_tab;  // fused path constant tables (lazy)

@@ -958,28 +958,14 @@ __global__ void __launch_bounds__(64 * kRRWaves, GL_RR_OCC) k_gl2048_regring(Ali
     const int l = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform
     // runs of all utterances are numbered consecutively, so only the last workgroup has idle waves
-    const int grun = blockIdx.x * kRRWaves + wave;
-    for (int i = threadIdx.x; i < kT2Entries * 64; i += 64 * kRRWaves) smem[i] = p.tab[i];
-    __syncthreads();
-    if (grun >= p.B * p.nruns) return;           // wave-uniform; no barrier after this point
+    // The first global loads of the run (ring fill, magnitudes of its first frame) are issued BEFORE the
+    // constant table is copied to LDS, so the two round trips to memory overlap; an idle wave of the last
+    // workgroup goes through the motions on run 0 and leaves after the barrier.
+    const int grun_raw = blockIdx.x * kRRWaves + wave;
+    const bool active = grun_raw < p.B * p.nruns;
+    const int grun = active ? grun_raw : 0;
     const int b = grun / p.nruns;
     const int run = grun - b * p.nruns;
-    v2f* ex = smem + kT2Entries * 64 + wave * kRScratch;
-    const v2f* tabl = smem + 2 * l;
-#if GL_TAB_REG == 1
-    // 2 waves per SIMD leave 256 VGPRs per lane: the 47 constants the frame loop uses live in registers
-    v2f treg[kT2A16F];
-#pragma unroll
-    for (int e = 0; e < kT2A16F; ++e) treg[e] = lds_rd(&tabl[TE(e)]);
-    const TabReg tb{treg};
-#elif GL_TAB_REG == 2
-    v2f treg[kT2Twp - kT2Tw1];
-#pragma unroll
-    for (int e = kT2Tw1; e < kT2Twp; ++e) treg[e - kT2Tw1] = lds_rd(&tabl[TE(e)]);
-    const TabMixed tb{tabl, treg};
-#else
-    const TabLds tb{tabl};
-#endif
     const int T = p.T;
     const int f0 = run * p.G;
     const int f1 = min(f0 + p.G, T);
@@ -1043,6 +1029,25 @@ __global__ void __launch_bounds__(64 * kRRWaves, GL_RR_OCC) k_gl2048_regring(Ali
     };
     float m_lo[9], m_hi[9];
     load_mags(f0, m_lo, m_hi);
+    for (int i = threadIdx.x; i < kT2Entries * 64; i += 64 * kRRWaves) smem[i] = p.tab[i];
+    __syncthreads();
+    if (!active) return;                         // wave-uniform; no barrier after this point
+    v2f* ex = smem + kT2Entries * 64 + wave * kRScratch;
+    const v2f* tabl = smem + 2 * l;
+#if GL_TAB_REG == 1
+    // 2 waves per SIMD leave 256 VGPRs per lane: the 47 constants the frame loop uses live in registers
+    v2f treg[kT2A16F];
+#pragma unroll
+    for (int e = 0; e < kT2A16F; ++e) treg[e] = lds_rd(&tabl[TE(e)]);
+    const TabReg tb{treg};
+#elif GL_TAB_REG == 2
+    v2f treg[kT2Twp - kT2Tw1];
+#pragma unroll
+    for (int e = kT2Tw1; e < kT2Twp; ++e) treg[e - kT2Tw1] = lds_rd(&tabl[TE(e)]);
+    const TabMixed tb{tabl, treg};
+#else
+    const TabLds tb{tabl};
+#endif
 #if GL_TW2_REG
     v2f w2reg[7];
 #pragma unroll

@@ -148,7 +148,9 @@ int gl_plan_set_options(gl_plan* plan, int flags, float momentum);
  * given run length; overlap-add sums at run seams associate differently for different run
  * lengths (last-bit differences), so pin it when outputs of different batch sizes -- e.g.
  * per-GPU shards vs. one big batch -- must be bit-identical.  Values below ceil((N-H)/H) are
- * raised to it.  No counterpart in the reference (a property of the GPU work split).          */
+ * raised to it.  A pinned value also keeps gl_run on the run kernels: unpinned, small problems
+ * (a few thousand frames) take a per-frame form whose results agree with them to rounding only.
+ * No counterpart in the reference (a property of the GPU work split).                          */
 int gl_plan_set_run_frames(gl_plan* plan, int frames);
 
 /* north_star (d): "the full N-iteration loop kept on-device on one HIP stream, and optionally

@@ -14,7 +14,8 @@
 //   k_gl2048_regring<HS> n_fft 2048, hop 128*HS: rings in registers, two frames in flight per wave
 //                        (the benchmark kernel)
 //   k_gl1024_pair / k_gl1024_pair2   n_fft 1024, any hop: two real frames per complex FFT, runs of frames per wave
-//   k_gl1024_frames<REACH> + k_ola1024   n_fft 1024, small problems: one frame pair per wave, state kept as frames
+//   k_gl1024_frames<REACH> + k_ola_frames   n_fft 1024, small problems: one frame pair per wave, state kept as frames
+//   k_gl2048_frames<HS>  n_fft 2048, hop 256*k, one or two utterances: one frame per wave, state kept as frames
 //   k_analysis2048       n_fft 2048: |centred STFT| of the forward analysis path (wav -> log-mel), one wave per frame
 // The FFT core (dft16/dft8, twiddle1/2, ex1_*/ex2_* transposes, middle_project) is shared.
 //
@@ -1239,6 +1240,121 @@ __global__ void __launch_bounds__(64 * kRRWaves, GL_RR_OCC) k_gl2048_regring(Ali
 
 
 // =====================================================================================
+// Small problems at n_fft 2048, hop 128*HS -- k_gl2048_frames<HS> + k_ola_frames.  Same idea as k_gl1024_frames
+// below: when B*T frames cannot fill the GPU with runs (one utterance; one rank's chunk of a long utterance), a
+// wave owns ONE frame, the state between iterations is the windowed inverse frames y[b][t][2048], and a wave
+// rebuilds its input frame from the previous iteration's y while loading it.  With the hop a multiple of the
+// 128-sample register row everything is row-granular and wave-uniform: row j of frame n is global row
+// R = n HS + j, covered by frames m = ceil((R-15)/HS) .. floor(R/HS) at their row R - m HS (ascending m, the order
+// of the reference's += loop) -- 16/HS terms per row, no per-lane conditions, one buffer load each with a
+// scalar offset.  Frames past either end of the utterance contribute zero rows.  Hop 128 (256 loads per lane) is
+// left to the run kernel.
+struct Frames2048Args {
+    const float* x_in;      // [B][L] start signal (first iteration) or null
+    const float* y_in;      // [B][T][2048] windowed inverse frames of the previous iteration (x_in == null)
+    const float* magp;      // [B][T][kMagPack] packed magnitudes (k_mag_repack)
+    float* y_out;           // [B][T][2048]
+    const v2f* tab;
+    int T, B;
+    long long L;
+};
+template <int HS>
+__global__ void __launch_bounds__(64 * kRRWaves) k_gl2048_frames(Frames2048Args p) {
+    __shared__ __attribute__((aligned(16))) v2f smem[kT2Entries * 64 + kRRWaves * kRScratch];
+    constexpr int H = 128 * HS;
+    const int l = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int T = p.T;
+    const long long gf_raw = (long long)blockIdx.x * kRRWaves + wave;
+    const bool active = gf_raw < (long long)p.B * T;
+    const long long gf = active ? gf_raw : 0;    // an idle wave of the last workgroup goes through the motions on frame 0
+    const int b = (int)(gf / T);
+    const int n = (int)(gf - (long long)b * T);
+
+    // operands first (one batch of loads), then the constant table, so the round trips overlap
+    float m_lo[9], m_hi[9];
+    {
+        const float* mrow = p.magp + ((long long)b * T + n) * kMagPack + 4 * l;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const v4f t = *reinterpret_cast<const v4f*>(mrow + 256 * q);
+            float* dst = (q < 2) ? m_lo + 4 * q : m_hi + 4 * (q - 2);
+            dst[0] = t.x; dst[1] = t.y; dst[2] = t.z; dst[3] = t.w;
+        }
+        m_lo[8] = mrow[1024 - 3 * l];
+        m_hi[8] = m_lo[8];
+    }
+    v2f z[16];
+    if (p.x_in != nullptr) {
+        const float* xr = p.x_in + (long long)b * p.L + (long long)n * H + 2 * l;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) z[j] = *reinterpret_cast<const v2f*>(xr + 128 * j);
+    } else {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.y_in + (long long)b * T * kN), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            z[j] = (v2f){0.0f, 0.0f};
+            // d = m - n from -floor((15 - j) / HS) to floor(j / HS), compile-time per j
+#pragma unroll
+            for (int d = -((15 - j) / HS); d <= j / HS; ++d) {
+                const int m = n + d;
+                const bool ok = m >= 0 && m < T;                      // wave-uniform
+                const int mc = ok ? m : n;
+                const int row = j - d * HS;                           // 0..15
+                // byte offset of (frame mc, row): below 2^31 for B*T*8 KB per utterance up to 2 GB
+                const int soff = (mc * kN + row * 128) * 4;
+                const v2f v = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rs, 8 * l, soff, 0));
+                z[j] += ok ? v : (v2f){0.0f, 0.0f};
+            }
+        }
+    }
+
+    for (int i = threadIdx.x; i < kT2Entries * 64; i += 64 * kRRWaves) smem[i] = p.tab[i];
+    __syncthreads();
+    if (!active) return;                         // wave-uniform; no barrier after this point
+    v2f* ex = smem + kT2Entries * 64 + wave * kRScratch;
+    const v2f* tabl = smem + 2 * l;
+    v2f treg[kT2Twp - kT2Tw1];
+#pragma unroll
+    for (int e = kT2Tw1; e < kT2Twp; ++e) treg[e - kT2Tw1] = lds_rd(&tabl[TE(e)]);
+    const TabMixed tb{tabl, treg};
+    const int a3 = l & 7, g3 = l >> 3;
+    const int kloB = l ? 128 - l : 64;
+    const bool l0 = (l == 0);
+
+#pragma unroll
+    for (int j = 0; j < 16; ++j) z[j] = z[j] * tb.get(kT2Win + j);
+    Stamps st;
+    fft_forward_1024(z, ex, l, a3, g3, kloB, tb, st);
+    middle_project(z, l0, m_lo, m_hi, tb);
+    fft_inverse_1024(z, ex, l, a3, g3, kloB, tb, st);
+    float* yo = p.y_out + ((long long)b * T + n) * kN + 2 * l;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const v2f w = tb.get(kT2Win + j);                             // 1/2048 is folded into the packed magnitudes
+        *reinterpret_cast<v2f*>(yo + 128 * j) = z[j] * w;
+    }
+}
+
+// x[b][s] = sum over frames m (ascending) of y[b][m][s - mH]: the overlap-add of audio_utilities.py:111-113 as a
+// gather; the last H samples no frame covers come out zero, like the reference's.
+__global__ void __launch_bounds__(256) k_ola_frames(const float* __restrict__ y, float* __restrict__ x, long long L, int N,
+                                                    int H, int T) {
+    const int b = blockIdx.y;
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= L) return;
+    const float* yb = y + (long long)b * T * N;
+    long long m_lo = (s - N + H) / H;             // ceil((s - N + 1) / H) for s - N + 1 > 0
+    if (s - N + 1 <= 0) m_lo = 0;
+    long long m_hi = s / H;
+    if (m_hi > T - 1) m_hi = T - 1;
+    float v = 0.0f;
+    for (long long m = m_lo; m <= m_hi; ++m) v += yb[m * N + (s - m * H)];
+    x[(long long)b * L + s] = v;
+}
+
+// =====================================================================================
 // n_fft = 1024, any hop (the reference's params.py defaults are 1024 / 275).
 //
 // Two consecutive REAL frames ride one 1024-point COMPLEX FFT: z = frame_a + i*frame_b.
@@ -1609,7 +1725,7 @@ __global__ void __launch_bounds__(64 * kP2Waves, 1) k_gl1024_pair2(Pair2Args pp)
 // previous iteration's y as it loads them,
 //     x[nH + i] = sum over frames m (ascending, the order of the reference's += loop) of y[m][(n - m)H + i],
 // (up to ceil(N/H) terms per sample, all L2 hits), so every pair of an iteration runs at once and there are no
-// run seams, tails or rings.  The first iteration reads the start signal instead; k_ola1024 folds the last y
+// run seams, tails or rings.  The first iteration reads the start signal instead; k_ola_frames folds the last y
 // into the output signal.  Results do not depend on any work split.
 constexpr int kF1Waves = 4;
 constexpr int kF1MaxReach = 8;               // frames a sample can reach back/forward: floor((N-1)/H) <= 8, H >= 114
@@ -1732,23 +1848,6 @@ __global__ void __launch_bounds__(64 * kF1Waves) k_gl1024_frames(Frames1024Args 
         ya[l + 64 * j] = z[j].x * w.x;
         if (two) ya[kN1 + l + 64 * j] = z[j].y * w.y;
     }
-}
-
-// x[b][s] = sum over frames m (ascending) of y[b][m][s - mH]: the overlap-add of audio_utilities.py:111-113 as a
-// gather; the last H samples no frame covers come out zero, like the reference's.
-__global__ void __launch_bounds__(256) k_ola1024(const float* __restrict__ y, float* __restrict__ x, long long L, int H,
-                                                 int T) {
-    const int b = blockIdx.y;
-    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= L) return;
-    const float* yb = y + (long long)b * T * kN1;
-    long long m_lo = (s - kN1 + H) / H;           // ceil((s - N + 1) / H) for s - N + 1 > 0
-    if (s - kN1 + 1 <= 0) m_lo = 0;
-    long long m_hi = s / H;
-    if (m_hi > T - 1) m_hi = T - 1;
-    float v = 0.0f;
-    for (long long m = m_lo; m <= m_hi; ++m) v += yb[m * kN1 + (s - m * H)];
-    x[(long long)b * L + s] = v;
 }
 
 // x[b][run*G*H + i] += tail[b][run-1][i], i < N-H, run = 1..nruns-1, in place: completes the signal between two
@@ -2053,6 +2152,15 @@ int launch_regring(const gl_plan* p, const AlignedArgs& a, int B, hipStream_t st
     return 0;
 }
 
+// Frames (B*T) up to which the per-frame form of n_fft 2048 is used (experiments: GL_F2_MAX_FRAMES).  Measured at
+// hop 256, T = 861 (us per iteration, per-frame form vs register-ring runs): B=1 22.0 / 34.6, B=2 23.4 / 35.0,
+// B=4 45.5 / 35.9, one 6 600-frame chunk 89.7 / 37.1: the run kernel scales far better (no 8-fold gather), so
+// the per-frame form is for one or two utterances only.
+static long long kF2MaxFrames(const gl_plan* p) {
+    static const char* e = getenv("GL_F2_MAX_FRAMES");
+    return e ? atoll(e) : 8LL * p->n_cu;
+}
+
 int run_regring(gl_plan* p, const float* mag, const float* x0, float* x_out, int iters, int B, int T,
                 hipStream_t st) {
     int rc = ensure_table2(p);
@@ -2066,6 +2174,43 @@ int run_regring(gl_plan* p, const float* mag, const float* x0, float* x_out, int
     }
     hipLaunchKernelGGL(k_mag_repack, dim3(T, B), dim3(64), 0, st, mag, p->d_magp, T);
     GL_HIP_CHECK(hipGetLastError());
+    // Too few frames to fill the GPU with runs: one wave per frame, state kept as frames (k_gl2048_frames).  Not
+    // with a pinned run length (callers who pin it compare bits with the run kernel) nor with the optional
+    // per-iteration signal transforms.
+    if (!gl_post_needed(p) && p->run_frames == 0 && !getenv("GL_RUN_FRAMES") && iters >= 1 && p->hop >= 256 && p->hop < kN &&
+        (long long)B * T <= kF2MaxFrames(p)) {
+        const size_t need = (size_t)2 * B * T * kN * sizeof(float);
+        if (p->yframes_bytes < need) {
+            // grown on demand, never under stream capture: gl_fast_prepare sizes it for the plan's maximum
+            if (p->d_yframes) { GL_HIP_CHECK(hipStreamSynchronize(st)); GL_HIP_CHECK(hipFree(p->d_yframes)); p->bytes -= (long long)p->yframes_bytes; p->d_yframes = nullptr; p->yframes_bytes = 0; }
+            rc = gl_plan_alloc(p, (void**)&p->d_yframes, need);
+            if (rc) return rc;
+            p->yframes_bytes = need;
+        }
+        Frames2048Args f = {};
+        f.magp = p->d_magp;
+        f.tab = reinterpret_cast<const v2f*>(p->d_fast_tab2);
+        f.T = T;
+        f.B = B;
+        f.L = gl_len(p->n_fft, p->hop, T);
+        float* ybuf[2] = {p->d_yframes, p->d_yframes + (size_t)B * T * kN};
+        const dim3 grid((unsigned)(((long long)B * T + kRRWaves - 1) / kRRWaves)), block(64 * kRRWaves);
+        for (int it = 0; it < iters; ++it) {
+            f.x_in = it == 0 ? x0 : nullptr;
+            f.y_in = it == 0 ? nullptr : ybuf[(it - 1) & 1];
+            f.y_out = ybuf[it & 1];
+            switch (p->hop / 128) {
+                case 2: hipLaunchKernelGGL(k_gl2048_frames<2>, grid, block, 0, st, f); break;
+                case 4: hipLaunchKernelGGL(k_gl2048_frames<4>, grid, block, 0, st, f); break;
+                default: hipLaunchKernelGGL(k_gl2048_frames<8>, grid, block, 0, st, f); break;
+            }
+            GL_HIP_CHECK(hipGetLastError());
+        }
+        hipLaunchKernelGGL(k_ola_frames, dim3((unsigned)((f.L + 255) / 256), B), dim3(256), 0, st, ybuf[(iters - 1) & 1],
+                           x_out, f.L, kN, p->hop, T);
+        GL_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     AlignedArgs a = {};
     a.magp = p->d_magp;
     a.tab = reinterpret_cast<const v2f*>(p->d_fast_tab2);
@@ -2178,8 +2323,8 @@ int run_pair1024(gl_plan* p, const float* mag, const float* x0, float* x_out, in
             }
             GL_HIP_CHECK(hipGetLastError());
         }
-        hipLaunchKernelGGL(k_ola1024, dim3((unsigned)((f.L + 255) / 256), B), dim3(256), 0, st, ybuf[(iters - 1) & 1], x_out,
-                           f.L, p->hop, T);
+        hipLaunchKernelGGL(k_ola_frames, dim3((unsigned)((f.L + 255) / 256), B), dim3(256), 0, st, ybuf[(iters - 1) & 1],
+                           x_out, f.L, kN1, p->hop, T);
         GL_HIP_CHECK(hipGetLastError());
         return 0;
     }
@@ -2309,6 +2454,14 @@ int gl_fast_prepare(gl_plan* p) {
         rc = ensure_table2(p);
         if (!rc && !p->d_magp)
             rc = gl_plan_alloc(p, (void**)&p->d_magp, (size_t)p->max_B * p->max_T * kMagPack * sizeof(float));
+        long long fr = (long long)p->max_B * p->max_T;
+        if (fr > kF2MaxFrames(p)) fr = kF2MaxFrames(p);
+        const size_t need = (size_t)2 * fr * kN * sizeof(float);              // per-frame form of small problems
+        if (!rc && p->hop >= 256 && p->yframes_bytes < need) {
+            if (p->d_yframes) { GL_HIP_CHECK(hipFree(p->d_yframes)); p->bytes -= (long long)p->yframes_bytes; p->d_yframes = nullptr; p->yframes_bytes = 0; }
+            rc = gl_plan_alloc(p, (void**)&p->d_yframes, need);
+            if (!rc) p->yframes_bytes = need;
+        }
     }
     return rc;
 }

@@ -643,3 +643,33 @@ def test_n1024_both_kernel_versions_on_small_cases(version):
     r = subprocess.run([sys.executable, os.path.join(here, "p1_version_check.py")], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_every_form_agrees_with_generic_on_random_geometries():
+    """gl_run picks its kernels from (n_fft, hop, B*T, pinned run length): per-frame forms for small problems,
+    run kernels otherwise.  Random small geometries, every hop class (reach 1..8 at 1024, every register-row
+    multiple and the general-hop kernel at 2048), auto selection and pinned run length, against the generic
+    kernels; few iterations so that rounding differences stay small."""
+    rng = np.random.default_rng(2026)
+    cases = []
+    for N in (1024, 2048):
+        hops = [114, 128, 200, 256, 275, 300, 384, 512, 640, 1000, 1024] if N == 1024 else [128, 256, 300, 512, 1024, 1500, 2048]
+        for H in hops:
+            for _ in range(3):
+                cases.append((N, H, int(rng.choice([1, 2, 3, 5, 8, 17, 40, 97, 230])), int(rng.choice([1, 2, 3, 7])),
+                              int(rng.choice([1, 2, 3, 4]))))
+    for (N, H, T, B, K) in cases:
+        mag = torch.from_numpy(np.abs(rng.standard_normal((B, T, N // 2 + 1))).astype(np.float32)).cuda()
+        x0 = torch.from_numpy(rng.standard_normal((B, T * H + N)).astype(np.float32)).cuda()
+        ref_p = _plan(N, H, T, B, 1)
+        ref = ref_p.run(mag, x0, K).cpu().numpy()
+        ref_p.close()
+        for pin in (0, 11):
+            p = Plan(N, H, T, B)
+            p.set_run_frames(pin)
+            got = p.run(mag, x0, K).cpu().numpy()
+            p.close()
+            assert np.isfinite(got).all()
+            assert peak_err(got, ref) <= 2e-4, (N, H, T, B, K, pin, peak_err(got, ref))
+            assert np.all(got[:, -H:] == 0.0), (N, H, T, B, K, pin)

@@ -75,9 +75,25 @@ __global__ void __launch_bounds__(kThreads) k_absmax(const float* __restrict__ x
     const int b = blockIdx.y;
     const float* row = x + (long long)b * row_stride;
     float m = 0.0f;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < len;
-         i += (long long)gridDim.x * blockDim.x)
-        m = fmaxf(m, fabsf(row[i]));
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nthr = (long long)gridDim.x * blockDim.x;
+    // 16-byte loads over the aligned body of the row (a streaming pass: 1.8 TB/s with dword loads), scalars for the rest
+    const long long n4 = ((reinterpret_cast<uintptr_t>(row) & 15) == 0) ? (len >> 2) : 0;
+    const float4* row4 = reinterpret_cast<const float4*>(row);
+    long long i4 = tid;
+    for (; i4 + 3 * nthr < n4; i4 += 4 * nthr) {                 // four independent loads in flight per thread
+        const float4 a = row4[i4], c = row4[i4 + nthr], d = row4[i4 + 2 * nthr], e = row4[i4 + 3 * nthr];
+        const float ma = fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w)));
+        const float mc = fmaxf(fmaxf(fabsf(c.x), fabsf(c.y)), fmaxf(fabsf(c.z), fabsf(c.w)));
+        const float md = fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), fabsf(d.w)));
+        const float me = fmaxf(fmaxf(fabsf(e.x), fabsf(e.y)), fmaxf(fabsf(e.z), fabsf(e.w)));
+        m = fmaxf(m, fmaxf(fmaxf(ma, mc), fmaxf(md, me)));
+    }
+    for (; i4 < n4; i4 += nthr) {
+        const float4 v = row4[i4];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    for (long long i = 4 * n4 + tid; i < len; i += nthr) m = fmaxf(m, fabsf(row[i]));
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
     __shared__ float wmax[kThreads / 64];
@@ -152,8 +168,10 @@ int gl_mask_launch(float* mag, const int* frames, int B, int T, int F, hipStream
 int gl_pcm16_launch(gl_plan* p, const float* x, long long row_stride, long long len, int16_t* pcm,
                     long long pcm_stride, float* peaks, int B, hipStream_t st) {
     GL_HIP_CHECK(hipMemsetAsync(p->d_peaks, 0, sizeof(unsigned) * (size_t)B, st));
-    long long blocks = (len + kThreads * 8 - 1) / (kThreads * 8);
-    if (blocks > 64) blocks = 64;
+    // about four workgroups per CU over the whole batch, each thread with several 16-byte loads in flight
+    long long blocks = (len + kThreads * 16 - 1) / (kThreads * 16);
+    const long long cap = (4LL * p->n_cu + B - 1) / B;
+    if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     dim3 grid((unsigned)blocks, B);
     hipLaunchKernelGGL(k_absmax, grid, dim3(kThreads), 0, st, x, row_stride, len, p->d_peaks);
@@ -187,8 +205,10 @@ int gl_randn_launch(float* out, long long n, uint64_t seed, long long offset, hi
 int gl_peak_launch(gl_plan* p, float* x, long long row_stride, long long len, float* peaks, int mode, int B,
                    hipStream_t st) {
     GL_HIP_CHECK(hipMemsetAsync(p->d_peaks, 0, sizeof(unsigned) * (size_t)B, st));
-    long long blocks = (len + kThreads * 8 - 1) / (kThreads * 8);
-    if (blocks > 64) blocks = 64;
+    // about four workgroups per CU over the whole batch, each thread with several 16-byte loads in flight
+    long long blocks = (len + kThreads * 16 - 1) / (kThreads * 16);
+    const long long cap = (4LL * p->n_cu + B - 1) / B;
+    if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     dim3 grid((unsigned)blocks, B);
     hipLaunchKernelGGL(k_absmax, grid, dim3(kThreads), 0, st, x, row_stride, len, p->d_peaks);

@@ -177,7 +177,7 @@ def _start_signal(B, L, x_init, seed, rng, plan, dev):
 
 def reconstruct_signal_griffin_lim(magnitude_spectrogram, fft_size, hopsamp, iterations, *,
                                    x_init=None, seed=None, rng="numpy", device=None, normalize=False,
-                                   momentum=0.0, lengths=None):
+                                   momentum=0.0, lengths=None, path=None, run_frames=None):
     """Griffin-Lim reconstruction (audio_utilities.py:154-188).
 
     magnitude_spectrogram: (T, F) or (B, T, F), rows = time slices.  The whole
@@ -186,7 +186,10 @@ def reconstruct_signal_griffin_lim(magnitude_spectrogram, fft_size, hopsamp, ite
     normalize / momentum (both off = the reference): window-sum normalised inverse STFT in every
     iteration; fast Griffin-Lim extrapolation x_n + momentum (x_n - x_{n-1}).
     lengths: frames per utterance of a ragged batch (B,); rows beyond them are ignored and utterance b
-    comes out as it would alone with lengths[b] frames, followed by zeros (see gl_mask_frames)."""
+    comes out as it would alone with lengths[b] frames, followed by zeros (see gl_mask_frames).
+    path / run_frames: for this call only -- 1 forces the generic any-N kernels; run_frames pins the fused
+    kernels' frames-per-wave-run, which makes results bit-identical across batch compositions (shards of a
+    batch vs the whole batch, chunks of a long utterance vs one piece)."""
     fft_size, hopsamp, iterations = int(fft_size), int(hopsamp), int(iterations)
     dev = _pick_device(device, magnitude_spectrogram, x_init)
     mag, was_np = _to_device(magnitude_spectrogram, dev, torch.float32)
@@ -210,7 +213,8 @@ def reconstruct_signal_griffin_lim(magnitude_spectrogram, fft_size, hopsamp, ite
             mag = mag.clone()            # never modify the caller's tensor
         plan.mask_frames(mag, lengths)
     x0 = _start_signal(B, L, x_init, seed, rng, plan, dev)
-    x = plan.run(mag, x0, iterations, out=x0, normalize=normalize, momentum=momentum)
+    x = plan.run(mag, x0, iterations, out=x0, normalize=normalize, momentum=momentum, path=path,
+                 run_frames=run_frames)
     if lengths is not None:
         _zero_past(x, lengths, hopsamp, fft_size)
     if single:
@@ -227,6 +231,9 @@ def pcm16_from_float(x):
     x = np.array(x, dtype=np.float64, copy=True)
     x_max = np.max(abs(x))
     assert x_max <= 1.0, 'Input audio value is out of range. Should be in the range [-1.0, 1.0].'
+    if x_max == 0 or not np.isfinite(x_max):
+        # the reference's x /= 0 gives NaN and int(round(nan)) raises (audio_utilities.py:204-209)
+        raise ValueError("cannot convert float NaN to integer")
     x /= x_max
     x *= 32767.0
     return np.rint(x).astype('<i2')

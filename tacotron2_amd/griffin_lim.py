@@ -46,7 +46,7 @@ def _device_filterbank(fb, dev):
 
 def mel_to_audio(mel_spectrogram, *, basis=None, n_fft=None, hop=None, iterations=None, x_init=None, seed=None,
                  rng="numpy", normalize="reference", device=None, window_sum_normalize=False, momentum=0.0,
-                 lengths=None):
+                 lengths=None, run_frames=None):
     """Batched core of save_mel_to_wav, everything on the GPU.
 
     mel_spectrogram: (n_mels, T) or (B, n_mels, T), numpy or torch (linear-amplitude
@@ -55,7 +55,8 @@ def mel_to_audio(mel_spectrogram, *, basis=None, n_fft=None, hop=None, iteration
     magnitudes clamped at 0 (north-star variant, not the reference).  window_sum_normalize /
     momentum / lengths (ragged batch: frames per utterance): see
     audio_utilities.reconstruct_signal_griffin_lim.  normalize: 'reference' (divide by the
-    peak only when it exceeds 1, griffin_lim.py:27-29), 'peak' (always) or None.
+    peak only when it exceeds 1, griffin_lim.py:27-29), 'peak' (always) or None.  run_frames: pin the
+    frames-per-wave-run for this call (shards of one batch then reproduce the whole batch bit for bit).
     Returns (waveforms (B, L) fp32 torch on device, magnitude (B, T, F) fp32 torch)."""
     n_fft = int(params.n_fft if n_fft is None else n_fft)
     hop = int(params.frame_hop if hop is None else hop)
@@ -95,7 +96,8 @@ def mel_to_audio(mel_spectrogram, *, basis=None, n_fft=None, hop=None, iteration
         plan.mask_frames(mag, lengths)
     L = plan.signal_length(T)
     x0 = audio_utilities._start_signal(B, L, x_init, seed, rng, plan, dev)
-    x = plan.run(mag, x0, iterations, out=x0, normalize=window_sum_normalize, momentum=momentum)   # :23-24
+    x = plan.run(mag, x0, iterations, out=x0, normalize=window_sum_normalize, momentum=momentum,
+                 run_frames=run_frames)                                                              # :23-24
     if lengths is not None:
         audio_utilities._zero_past(x, lengths, hop, n_fft)
     if normalize == "reference":

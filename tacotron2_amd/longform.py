@@ -298,20 +298,19 @@ def reconstruct_signal_griffin_lim_longform(magnitude_spectrogram, fft_size, hop
         W, M = 0, max(K, 1)
     chunks = plan_chunks(T, C, W, N, H, align=run_frames or 1)
 
-    mags, plans = {}, {}
+    # one shared plan sized for the longest chunk; the run-length pin travels with each call (never plan state)
+    longest = max(chunks[c].lb - chunks[c].la for c in mine)
+    plan = get_plan(N, H, longest, 1, dev)
+    mags = {}
     for c in mine:
         ch = chunks[c]
-        plans[c] = get_plan(N, H, ch.lb - ch.la, 1, dev)
-        plans[c].set_run_frames(run_frames or 0)
         mags[c] = rows(ch.la, ch.lb).reshape(1, ch.lb - ch.la, F).contiguous()
 
     def step(ch, x_local, n):
-        plan = get_plan(N, H, ch.lb - ch.la, 1, dev)
-        plan.set_run_frames(run_frames or 0)
-        return plan.run(mags[ch.index], x_local, n, out=x_local)
+        return plan.run(mags[ch.index], x_local, n, out=x_local, run_frames=run_frames or 0)
 
     def stitch(out, piece, offset, fade_in, fade_out):
-        plans[mine[0]].stitch_add(out, piece, offset, fade_in, fade_out)
+        plan.stitch_add(out, piece, offset, fade_in, fade_out)
 
     drv = LongformDriver(N, H, T, chunks, mine, step, stitch, group)
 
@@ -343,7 +342,7 @@ def reconstruct_signal_griffin_lim_longform(magnitude_spectrogram, fft_size, hop
         elif host0 is not None:
             x0 = torch.from_numpy(host0[lo:hi]).to(dev)
         else:
-            x0 = plans[c].randn((hi - lo,), 0 if seed is None else seed, offset=lo)
+            x0 = plan.randn((hi - lo,), 0 if seed is None else seed, offset=lo)
         drv.set_signal(ch, x0.reshape(1, hi - lo))
 
     drv.run(K, M)

@@ -3,6 +3,7 @@
 PyTorch-ROCm is used only for device memory and streams; all compute goes
 through the C-ABI in include/gl_hip.h.
 """
+import contextlib
 import ctypes
 import threading
 
@@ -39,6 +40,9 @@ class Plan:
         self.n_bins = self.n_fft // 2 + 1
         self._h = ctypes.c_void_p()
         self._lib = _lib.lib()
+        self._path = 0            # plan defaults; Plan.run(path=..., run_frames=...) overrides them for ONE call
+        self._run_frames = 0
+        self._shared = False      # True for plans handed out by get_plan(): their defaults are frozen
         _lib.check(self._lib.gl_plan_create(self.n_fft, self.hop, self.max_frames, self.max_batch,
                                             self.device.index, ctypes.byref(self._h)), "gl_plan_create")
 
@@ -62,13 +66,48 @@ class Plan:
         return int(self._lib.gl_plan_device_bytes(self._h))
 
     def set_path(self, path):
-        """0 = auto (fused kernels where available), 1 = force the generic kernels."""
-        _lib.check(self._lib.gl_plan_set_path(self._h, int(path)), "gl_plan_set_path")
+        """Plan default: 0 = auto (fused kernels where available), 1 = force the generic kernels.
+        Plans from get_plan() are shared between callers: pass path= to the call instead."""
+        self._not_shared("set_path")
+        self._set_path(path)
 
     def set_run_frames(self, frames):
-        """Pin the frames-per-wave-run of the fused kernels (0 = automatic).  Pin it when results
-        for different batch sizes (per-GPU shards vs one batch) must be bit-identical."""
+        """Plan default for the frames-per-wave-run of the fused kernels (0 = automatic).  Pin it when
+        results for different batch sizes (per-GPU shards vs one batch) must be bit-identical.
+        Plans from get_plan() are shared between callers: pass run_frames= to the call instead."""
+        self._not_shared("set_run_frames")
+        self._set_run_frames(frames)
+
+    def _not_shared(self, what):
+        if self._shared:
+            raise RuntimeError(f"{what}() on a plan from get_plan(): the cache hands the same plan to every caller "
+                               "of this geometry, so its defaults stay as they are -- pass path= / run_frames= to "
+                               "the call (they apply to that call only) or create a private Plan")
+
+    def _set_path(self, path):
+        _lib.check(self._lib.gl_plan_set_path(self._h, int(path)), "gl_plan_set_path")
+        self._path = int(path)
+
+    def _set_run_frames(self, frames):
         _lib.check(self._lib.gl_plan_set_run_frames(self._h, int(frames)), "gl_plan_set_run_frames")
+        self._run_frames = int(frames)
+
+    @contextlib.contextmanager
+    def _scoped(self, path=None, run_frames=None):
+        """path / run_frames for the calls inside the block only; the plan's own values come back afterwards,
+        also when a call raises."""
+        old = (self._path, self._run_frames)
+        try:
+            if path is not None and int(path) != old[0]:
+                self._set_path(path)
+            if run_frames is not None and int(run_frames) != old[1]:
+                self._set_run_frames(run_frames)
+            yield self
+        finally:
+            if self._path != old[0]:
+                self._set_path(old[0])
+            if self._run_frames != old[1]:
+                self._set_run_frames(old[1])
 
     def set_options(self, window_sum_normalize=False, clamp_mag=False, momentum=0.0):
         """Off-by-default variants (gl_plan_set_options); the defaults are the reference's behaviour."""
@@ -163,9 +202,11 @@ class Plan:
                                                 _stream_ptr(self.device)), "gl_mask_frames")
         return lens
 
-    def run(self, mag, x0, iterations, out=None, normalize=False, momentum=0.0):
+    def run(self, mag, x0, iterations, out=None, normalize=False, momentum=0.0, path=None, run_frames=None):
         """mag (B, T, F), x0 (B, L) -> x (B, L) after `iterations` Griffin-Lim iterations.
-        normalize / momentum: window-sum normalised ISTFT, fast Griffin-Lim (not in the reference)."""
+        normalize / momentum: window-sum normalised ISTFT, fast Griffin-Lim (not in the reference).
+        path / run_frames: kernel family and frames-per-wave-run for THIS call (None = the plan's default);
+        they never outlive the call."""
         self.set_options(window_sum_normalize=normalize, momentum=momentum)
         B, T, F = mag.shape
         if F != self.n_bins:
@@ -173,7 +214,7 @@ class Plan:
         L = self.signal_length(T)
         if out is None:
             out = torch.empty((B, L), dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
+        with self._scoped(path, run_frames), torch.cuda.device(self.device):
             _lib.check(self._lib.gl_run(self._h, self._f32(mag), self._f32(x0, (B, L)), self._f32(out, (B, L)),
                                         int(iterations), B, T, _stream_ptr(self.device)), "gl_run")
         return out
@@ -302,6 +343,7 @@ def get_plan(n_fft, hop, frames, batch, device=None):
                 torch.cuda.synchronize(dev)
                 p.close()
             p = Plan(n_fft, hop, mf, mb, dev)
+            p._shared = True
             _cache[key] = p
         return p
 

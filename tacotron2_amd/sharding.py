@@ -20,12 +20,12 @@ def shard_bounds(n_items, world_size, rank):
     return lo, hi
 
 
-def shard_batch(batch, world_size=None, rank=None):
-    """Slice dim 0 of `batch` (tensor or ndarray) for this rank."""
+def shard_batch(batch, world_size=None, rank=None, group=None):
+    """Slice dim 0 of `batch` (tensor or ndarray) for this rank (of `group`, default: the world)."""
     if world_size is None:
-        world_size = dist.get_world_size() if dist.is_initialized() else 1
+        world_size = dist.get_world_size(group) if dist.is_initialized() else 1
     if rank is None:
-        rank = dist.get_rank() if dist.is_initialized() else 0
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
     lo, hi = shard_bounds(len(batch), world_size, rank)
     return batch[lo:hi]
 
@@ -55,5 +55,5 @@ def reconstruct_sharded(mels, reconstruct_fn, gather=True, group=None):
     """Run `reconstruct_fn(local_mels) -> (n_local, L) tensor` on this rank's shard of `mels`
     (B, n_mels, T) and optionally gather the waveforms of the whole batch."""
     n_total = len(mels)
-    local = reconstruct_fn(shard_batch(mels))
+    local = reconstruct_fn(shard_batch(mels, group=group))
     return gather_waveforms(local, n_total, group) if gather else local

@@ -283,12 +283,10 @@ def test_config2_full_size_properties_and_parity():
     # bit-identical rows need the same work split: with the frames-per-wave split pinned both calls run the run
     # kernel with the same runs (unpinned, one utterance of 861 frames takes the per-frame form of small problems
     # and agrees to rounding only)
-    p.set_run_frames(27)
-    y = p.run(mag, x0, K)
-    y1 = p.run(mag[1:2].contiguous(), x0[1:2].contiguous(), K)
+    y = p.run(mag, x0, K, run_frames=27)
+    y1 = p.run(mag[1:2].contiguous(), x0[1:2].contiguous(), K, run_frames=27)
     assert torch.equal(y1[0], y[1])
-    p.set_run_frames(0)
-    y1f = p.run(mag[1:2].contiguous(), x0[1:2].contiguous(), K)
+    y1f = p.run(mag[1:2].contiguous(), x0[1:2].contiguous(), K)      # the pin did not outlive its call
     assert peak_err(y1f[0].cpu().numpy(), y[1].cpu().numpy()) <= 1e-4
     assert torch.all(y[:, -H:] == 0) and torch.all(y1f[:, -H:] == 0)
     mag0 = mag[0].cpu().numpy().astype(np.float64)
@@ -299,6 +297,50 @@ def test_config2_full_size_properties_and_parity():
     assert abs(sc - sc_ref) <= 1e-3
     sc0 = orc.spectral_convergence(x0[0].cpu().numpy().astype(np.float64), mag0, N, H)
     assert sc < sc0
+
+
+def test_config3_shard_of_128_is_a_slice_of_the_1024_batch():
+    """BASELINE config 3: ONE batch of 1024 utterances sharded per utterance over 8 GPUs.  Utterances are generated
+    from their GLOBAL index (bench.synth_mels_by_id; start signal = elements [id*L, (id+1)*L) of one Philox stream),
+    so rank 3's 128 are a slice of the 1024-batch.  The full shard runs at its real size (B=128, T=861, 60
+    iterations, run length pinned like a sharded job pins it): rows are bit-identical to single-utterance runs and to
+    the same utterances inside a DIFFERENT shard composition, and two rows are held to the float64 oracle."""
+    from bench import synth_mels_by_id
+    from tacotron2_amd.sharding import shard_bounds
+    N, H, T, K, G, world, rank, pin = 2048, 256, 861, 60, 1024, 8, 3, 27
+    L = T * H + N
+    lo, hi = shard_bounds(G, world, rank)
+    assert (lo, hi) == (384, 512)
+    B = hi - lo
+    fb = torch.from_numpy(filters.mel(22050, N, 80, 125, 7600)).cuda()
+    p = get_plan(N, H, T, B)
+    mel = torch.from_numpy(synth_mels_by_id(range(lo, hi), T)).cuda()
+    x0 = p.randn((B, L), seed=42, offset=lo * L)
+    mag = p.mel_to_mag(fb, mel)
+    y = p.run(mag, x0, K, run_frames=pin)
+    assert torch.isfinite(y).all() and torch.all(y[:, -H:] == 0)
+    # the same utterances generated and run alone, from their global ids only
+    for gid in (lo, lo + 77, hi - 1):
+        m1 = torch.from_numpy(synth_mels_by_id([gid], T)).cuda()
+        assert torch.equal(m1[0], mel[gid - lo])
+        x1 = p.randn((1, L), seed=42, offset=gid * L)
+        assert torch.equal(x1[0], x0[gid - lo])
+        y1 = p.run(p.mel_to_mag(fb, m1), x1, K, run_frames=pin)
+        assert torch.equal(y1[0], y[gid - lo]), gid
+    # ... and inside another split of the same 1024 (4 ranks: rank 1 holds 256..511)
+    lo4, hi4 = shard_bounds(G, 4, 1)
+    sub = slice(lo - lo4, lo - lo4 + 64)                       # 64 utterances of it, to keep the test short
+    ids = range(lo4 + sub.start, lo4 + sub.stop)
+    y4 = p.run(p.mel_to_mag(fb, torch.from_numpy(synth_mels_by_id(ids, T)).cuda()),
+               p.randn((64, L), seed=42, offset=ids[0] * L), K, run_frames=pin)
+    assert torch.equal(y4, y[ids[0] - lo:ids[0] - lo + 64])
+    # parity of the shard against the oracle (the reference's algorithm in float64) on two of its rows
+    for r in (5, 127):
+        mi = mag[r].cpu().numpy().astype(np.float64)
+        ref = orc.griffin_lim_vec(mi, N, H, K, x0[r].cpu().numpy().astype(np.float64))
+        got = y[r].cpu().numpy().astype(np.float64)
+        assert peak_err(got, ref) <= TOL_GL
+        assert abs(orc.spectral_convergence(got, mi, N, H) - orc.spectral_convergence(ref, mi, N, H)) <= 1e-3
 
 
 def test_ill_conditioned_input_tracks_oracle_while_conditioning_allows():
@@ -356,11 +398,9 @@ def test_config5_geometry_batch32():
     y7 = p.run(mag[7:8].contiguous(), x0[7:8].contiguous(), K)
     assert peak_err(y7[0].cpu().numpy(), y[7].cpu().numpy()) <= 3e-4     # 60 iterations amplify the seams' rounding
     # ... and bit for bit once the run length is pinned (what a sharded multi-GPU job does)
-    p.set_run_frames(32)
-    yp = p.run(mag, x0, K)
-    y7 = p.run(mag[7:8].contiguous(), x0[7:8].contiguous(), K)
+    yp = p.run(mag, x0, K, run_frames=32)
+    y7 = p.run(mag[7:8].contiguous(), x0[7:8].contiguous(), K, run_frames=32)
     assert torch.equal(y7[0], yp[7])
-    p.set_run_frames(0)
     for i in (0, 31):
         mi = mag[i].cpu().numpy().astype(np.float64)
         ref = orc.griffin_lim_vec(mi, N, H, K, x0[i].cpu().numpy().astype(np.float64))
@@ -616,33 +656,65 @@ def test_ragged_batch_equals_per_utterance_runs(N, H, path):
     rng = np.random.default_rng(61)
     mag = np.abs(rng.standard_normal((len(lens), T, F))).astype(np.float32)          # rows past lens[b]: garbage
     x0 = rng.standard_normal((len(lens), T * H + N)).astype(np.float32)
-    get_plan(N, H, T, len(lens), "cuda:0").set_path(path)
     x = au.reconstruct_signal_griffin_lim(torch.from_numpy(mag), N, H, K, x_init=torch.from_numpy(x0), lengths=lens,
-                                          device="cuda:0").cpu().numpy()
+                                          device="cuda:0", path=path).cpu().numpy()
     for b, tb in enumerate(lens):
         Lb = tb * H + N
         ref = orc.griffin_lim_vec(mag[b, :tb].astype(np.float64), N, H, K, x0[b, :Lb].astype(np.float64))
         assert np.max(np.abs(x[b, :Lb] - ref)) <= 1e-3 * np.max(np.abs(ref))
         assert not x[b, Lb:].any()
         alone = au.reconstruct_signal_griffin_lim(torch.from_numpy(mag[b, :tb]), N, H, K,
-                                                  x_init=torch.from_numpy(x0[b, :Lb]), device="cuda:0").cpu().numpy()
+                                                  x_init=torch.from_numpy(x0[b, :Lb]), device="cuda:0",
+                                                  path=path).cpu().numpy()
         assert np.max(np.abs(x[b, :Lb] - alone)) <= 2e-5 * np.max(np.abs(alone))
-    get_plan(N, H, T, len(lens), "cuda:0").set_path(0)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("version", ["1", "2", "f"])
-def test_n1024_both_kernel_versions_on_small_cases(version):
-    """gl_run picks the n_fft-1024 kernel version by problem size; force each one (GL_P1_VERSION is read once
-    per process, hence the subprocess) over small cases with tails, odd frame counts and a zero frame."""
-    import os
-    import subprocess
-    import sys
-    here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, GL_P1_VERSION=version)
-    r = subprocess.run([sys.executable, os.path.join(here, "p1_version_check.py")], env=env,
-                       capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+@pytest.mark.parametrize("form", ["runs", "auto"])
+def test_n1024_both_forms_on_small_cases(form):
+    """gl_run picks the n_fft-1024 kernel by problem size and pin: the run kernel (k_gl1024_pair2) whenever the run
+    length is pinned, the per-pair frames form (k_gl1024_frames) for small unpinned problems.  Both over small cases
+    with seams between runs, odd frame counts, every reach floor(1023/H) = 1..8 of the per-pair form (hop 100 has
+    10: run kernel either way) and an all-zero frame next to a live one, against the float64 oracle."""
+    N = 1024
+    for (H, B, T, K, G) in [(275, 2, 41, 6, 5), (275, 1, 7, 3, 4), (256, 3, 64, 5, 6), (100, 1, 30, 4, 11), (275, 2, 1, 2, 3),
+                            (512, 2, 9, 3, 2), (400, 1, 12, 3, 4), (220, 1, 19, 3, 6), (200, 1, 33, 4, 8), (170, 2, 14, 3, 7),
+                            (146, 1, 25, 3, 9), (128, 1, 40, 3, 10), (114, 2, 21, 2, 12), (1024, 1, 5, 2, 1)]:
+        rng = np.random.default_rng(T + H)
+        mag = np.abs(rng.standard_normal((B, T, N // 2 + 1))).astype(np.float32)
+        x0 = rng.standard_normal((B, T * H + N)).astype(np.float32)
+        if T > 8:
+            x0[0, 3 * H:3 * H + N] = 0.0      # frame 3 of utterance 0 is exactly zero at the first iteration
+        p = Plan(N, H, T, B, "cuda:0")
+        x = p.run(torch.from_numpy(mag).cuda(), torch.from_numpy(x0).cuda(), K,
+                  run_frames=G if form == "runs" else 0).cpu().numpy()
+        p.close()
+        for b in range(B):
+            ref = orc.griffin_lim_vec(mag[b].astype(np.float64), N, H, K, x0[b].astype(np.float64))
+            assert peak_err(x[b], ref) <= TOL_GL, (form, H, B, T, K, G)
+
+
+def test_shared_plans_refuse_sticky_settings_and_per_call_pins_do_not_leak():
+    """Plans from get_plan() are shared by every caller of a geometry: their defaults cannot be changed, and a
+    path / run-length passed to one call is gone at the next."""
+    N, H, T = 2048, 256, 60
+    p = get_plan(N, H, T, 1)
+    with pytest.raises(RuntimeError):
+        p.set_run_frames(9)
+    with pytest.raises(RuntimeError):
+        p.set_path(1)
+    rng = np.random.default_rng(3)
+    mag = torch.from_numpy(np.abs(rng.standard_normal((1, T, N // 2 + 1))).astype(np.float32)).cuda()
+    x0 = torch.from_numpy(rng.standard_normal((1, T * H + N)).astype(np.float32)).cuda()
+    auto_before = p.run(mag, x0, 3).clone()
+    pinned = p.run(mag, x0, 3, run_frames=9).clone()
+    generic = p.run(mag, x0, 3, path=1).clone()
+    with pytest.raises(ValueError):                       # a failing call restores the plan too
+        p.run(mag[:, :, :-1].contiguous(), x0, 3, run_frames=9, path=1)
+    assert (p._path, p._run_frames) == (0, 0)
+    assert torch.equal(p.run(mag, x0, 3), auto_before)
+    assert peak_err(pinned.cpu().numpy(), auto_before.cpu().numpy()) <= 2e-5
+    assert peak_err(generic.cpu().numpy(), auto_before.cpu().numpy()) <= 2e-5
 
 
 @pytest.mark.gpu

@@ -18,6 +18,9 @@ def test_pcm16_known_answers(golden):
     assert np.array_equal(au.pcm16_from_float(d["x"]), orc.pcm16_from_float(d["x"]))
     with pytest.raises(AssertionError):
         au.pcm16_from_float(np.array([0.0, -1.01]))
+    # all-zero input: the reference's x /= 0 gives NaN and int(round(nan)) raises ValueError (lines 204-209)
+    with pytest.raises(ValueError):
+        au.pcm16_from_float(np.zeros(8))
 
 
 def test_save_audio_to_file_bytes(tmp_path, capsys):

@@ -74,3 +74,39 @@ def test_world_size_2_sharded_equals_unsharded(n_items):
     for _, _, _, full in results:
         assert full.shape == ref.shape
         assert np.array_equal(full, ref)          # bitwise: sharding changes nothing
+
+
+def _subgroup_worker(rank, world, port, n_items, members, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        grp = dist.new_group(members)             # every rank takes part in creating it
+        if rank in members:
+            rng = np.random.default_rng(5)
+            mels = rng.standard_normal((n_items, 4, 6)).astype(np.float32)
+            full = sharding.reconstruct_sharded(mels, _fake_reconstruct, gather=True, group=grp)
+            q.put((rank, full.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sub_group_shards_and_gathers_by_group_rank():
+    """A job that gives Griffin-Lim a sub-group of the world (ranks 2 and 0 of 3, in that order): shard bounds and
+    the gather both follow the GROUP's size and ranks."""
+    world, members, n_items = 3, [2, 0], 7
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_subgroup_worker, args=(r, world, port, n_items, members, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in members]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(5)
+    ref = _fake_reconstruct(rng.standard_normal((n_items, 4, 6)).astype(np.float32)).numpy()
+    assert sorted(r for r, _ in results) == [0, 2]
+    for _, full in results:
+        assert np.array_equal(full, ref)

@@ -197,6 +197,22 @@ int gl_stitch_add(float* out, long long out_len, const float* chunk, long long c
 int gl_peak_normalise(gl_plan* plan, float* x, long long row_stride, long long len,
                       float* peaks, int mode, int B, void* stream);
 
+/* No-allocation variant of gl_peak_normalise.  NO COUNTERPART IN THE REFERENCE (griffin_lim.py:27-29 is three
+ * numpy lines): it exists for callers that cannot allocate device memory -- code under hipGraph / stream
+ * capture, tight serving loops, harnesses that forbid hipMalloc -- and therefore cannot create a gl_plan
+ * (gl_plan_create allocates).  Same arguments, kernels and results as gl_peak_normalise, bit for bit, but the
+ * per-row maxima the two kernels exchange live in a file-scope device array of GL_STATIC_MAX_BATCH entries
+ * (16 KB, held by every GPU the library runs on until the process ends) instead of plan-owned memory, and
+ * `device` names the GPU the buffers are on instead of a plan.  The call makes no hipMalloc / hipFree or any
+ * other allocating call; the first call on a device looks the array's address up once
+ * (hipGetSymbolAddress).  B > GL_STATIC_MAX_BATCH is rejected with GL_ERR_INVALID.  All calls on one GPU
+ * share the array (it keeps the last call's maxima; each call clears the B entries it uses first on
+ * `stream`), so calls that overlap in time on one GPU -- different streams, or threads -- race: order them
+ * on one stream.                                                                                        */
+#define GL_STATIC_MAX_BATCH 4096
+int gl_peak_normalise_static(float* x, long long row_stride, long long len, float* peaks, int mode, int B,
+                             int device, void* stream);
+
 /* N2 / a-7  sample conversion of save_audio_to_file            audio_utilities.py:202-210
  *   x_max = max|x|; x /= x_max; x *= 32767; int(round(x[i]))  -- in float64 with round-half-even like
  *   the reference, so the bytes match it for the same input samples.

@@ -3,6 +3,9 @@
 The library is built in-tree by ``tacotron2_amd/csrc/Makefile`` (or
 ``__graft_entry__.build()``).  There is no CPU fallback: if the shared object is
 missing or a symbol is absent, importing this module's ``lib()`` raises.
+
+The one environment variable the package reads is ``GL_HIP_LIB``: the path of another build of the
+same library (the kernel-study builds of ``abl/build.sh``).  The HIP sources read none.
 """
 import ctypes
 import os
@@ -51,6 +54,8 @@ SIGNATURES = {
                                      ctypes.c_longlong, ctypes.c_longlong, ctypes.c_void_p]),
     "gl_peak_normalise": (ctypes.c_int, [_plan_p, _c_float_p, ctypes.c_longlong, ctypes.c_longlong, _c_float_p,
                                          ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "gl_peak_normalise_static": (ctypes.c_int, [_c_float_p, ctypes.c_longlong, ctypes.c_longlong, _c_float_p,
+                                                ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "gl_pcm16_encode": (ctypes.c_int, [_plan_p, _c_float_p, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_void_p,
                                        ctypes.c_longlong, _c_float_p, ctypes.c_int, ctypes.c_void_p]),
 }

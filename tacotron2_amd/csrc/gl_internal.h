@@ -43,9 +43,11 @@ int gl_set_error(int code, const char* fmt, ...);
 #define GL_HIP_CHECK(expr)                                                            \
     do {                                                                              \
         hipError_t e_ = (expr);                                                       \
-        if (e_ != hipSuccess)                                                         \
+        if (e_ != hipSuccess) {                                                       \
+            (void)hipGetLastError(); /* reported here: do not leave it for the next caller of the runtime */ \
             return gl_set_error(GL_ERR_HIP, "%s failed: %s (%s:%d)", #expr,           \
                                 hipGetErrorString(e_), __FILE__, __LINE__);           \
+        }                                                                             \
     } while (0)
 
 static inline long long gl_len(int N, int H, int T) { return (long long)T * H + N; }
@@ -93,6 +95,9 @@ int gl_stitch_launch(float* out, long long out_len, const float* chunk, long lon
                      long long fade_in, long long fade_out, hipStream_t st);
 int gl_peak_launch(gl_plan* p, float* x, long long row_stride, long long len, float* peaks, int mode, int B,
                    hipStream_t st);
+int gl_static_scratch_setup(int device, unsigned** ptr, int* n_cu);   // gl_peak_normalise_static
+int gl_peak_launch_on(unsigned* d_peaks, int n_cu, float* x, long long row_stride, long long len, float* peaks,
+                      int mode, int B, hipStream_t st);
 int gl_mask_launch(float* mag, const int* frames, int B, int T, int F, hipStream_t st);
 int gl_copy_rows(float* dst, const float* src, long long n, hipStream_t st);
 int gl_pcm16_launch(gl_plan* p, const float* x, long long row_stride, long long len, int16_t* pcm,

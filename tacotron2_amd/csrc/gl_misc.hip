@@ -1,5 +1,7 @@
 // Small streaming kernels around the Griffin-Lim loop: device RNG for the start
 // signal, per-utterance peak normalisation, row copy.
+#include <mutex>
+
 #include "gl_internal.h"
 
 namespace {
@@ -202,24 +204,90 @@ int gl_randn_launch(float* out, long long n, uint64_t seed, long long offset, hi
     return 0;
 }
 
-int gl_peak_launch(gl_plan* p, float* x, long long row_stride, long long len, float* peaks, int mode, int B,
-                   hipStream_t st) {
-    GL_HIP_CHECK(hipMemsetAsync(p->d_peaks, 0, sizeof(unsigned) * (size_t)B, st));
-    // about four workgroups per CU over the whole batch, each thread with several 16-byte loads in flight
+// ---- peak normalisation without any allocation (gl_peak_normalise_static) --------------------
+// The per-row maxima k_absmax / k_peak_scale exchange are the only device memory gl_peak_normalise
+// needs beyond its operands; here they live in a file-scope device array instead of the plan, so a
+// caller that may not allocate (stream capture, serving loops) needs no plan at all.  `scratch` is
+// the host-side handle of the array only: host code uses the per-device address hipGetSymbolAddress
+// returned (every GPU holds its own copy at its own address).
+static __device__ __align__(256) unsigned scratch[GL_STATIC_MAX_BATCH];     // 16 KB per GPU, held until exit
+
+namespace {
+constexpr int kMaxDevices = 64;
+struct StaticScratch {
+    unsigned* ptr;
+    int n_cu;
+};
+StaticScratch g_static[kMaxDevices];
+std::mutex g_static_mutex;
+}  // namespace
+
+// Once per device, with that device current: the array's address on it and its CU count.
+int gl_static_scratch_setup(int device, unsigned** ptr, int* n_cu) {
+    if (device < 0 || device >= kMaxDevices)
+        return gl_set_error(GL_ERR_INVALID, "device %d outside [0, %d)", device, kMaxDevices);
+    std::lock_guard<std::mutex> lock(g_static_mutex);
+    StaticScratch& s = g_static[device];
+    if (!s.ptr) {
+        unsigned* q = nullptr;
+        GL_HIP_CHECK(hipGetSymbolAddress((void**)&q, HIP_SYMBOL(scratch)));
+        if (!q) return gl_set_error(GL_ERR_HIP, "hipGetSymbolAddress returned a null address on device %d", device);
+        int cus = 0;
+        GL_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+        s.n_cu = cus > 0 ? cus : 256;
+        s.ptr = q;
+    }
+    *ptr = s.ptr;
+    *n_cu = s.n_cu;
+    return 0;
+}
+
+int gl_peak_launch_on(unsigned* d_peaks, int n_cu, float* x, long long row_stride, long long len, float* peaks,
+                          int mode, int B, hipStream_t st) {
+    // the maxima buffer keeps the last call's values: the B entries this call uses start at zero
+    GL_HIP_CHECK(hipMemsetAsync(d_peaks, 0, sizeof(unsigned) * (size_t)B, st));
     long long blocks = (len + kThreads * 16 - 1) / (kThreads * 16);
-    const long long cap = (4LL * p->n_cu + B - 1) / B;
+    const long long cap = (4LL * n_cu + B - 1) / B;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     dim3 grid((unsigned)blocks, B);
-    hipLaunchKernelGGL(k_absmax, grid, dim3(kThreads), 0, st, x, row_stride, len, p->d_peaks);
+    hipLaunchKernelGGL(k_absmax, grid, dim3(kThreads), 0, st, x, row_stride, len, d_peaks);
     GL_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(k_peak_scale, grid, dim3(kThreads), 0, st, x, row_stride, len, p->d_peaks, peaks, mode);
+    hipLaunchKernelGGL(k_peak_scale, grid, dim3(kThreads), 0, st, x, row_stride, len, d_peaks, peaks, mode);
     GL_HIP_CHECK(hipGetLastError());
     return 0;
+}
+
+int gl_peak_launch(gl_plan* p, float* x, long long row_stride, long long len, float* peaks, int mode, int B,
+                   hipStream_t st) {
+    return gl_peak_launch_on(p->d_peaks, p->n_cu, x, row_stride, len, peaks, mode, B, st);
 }
 
 int gl_copy_rows(float* dst, const float* src, long long n, hipStream_t st) {
     if (dst == src || n <= 0) return 0;
     GL_HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, st));
     return 0;
+}
+
+// ---- the no-allocation entry point (include/gl_hip.h) ------------------------------------------
+extern "C" int gl_peak_normalise_static(float* x, long long row_stride, long long len, float* peaks, int mode, int B,
+                                        int device, void* stream) {
+    if (!x) return gl_set_error(GL_ERR_INVALID, "gl_peak_normalise_static: x is NULL");
+    if (B < 1 || B > GL_STATIC_MAX_BATCH)
+        return gl_set_error(GL_ERR_INVALID, "gl_peak_normalise_static: B=%d outside [1, %d] (the static scratch "
+                            "array holds GL_STATIC_MAX_BATCH row maxima)", B, GL_STATIC_MAX_BATCH);
+    if (len < 1 || row_stride < len || (mode != 0 && mode != 1))
+        return gl_set_error(GL_ERR_INVALID, "gl_peak_normalise_static: bad len/stride/mode");
+    int ndev = 0, prev = -1;
+    GL_HIP_CHECK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev)
+        return gl_set_error(GL_ERR_INVALID, "gl_peak_normalise_static: device %d out of range (%d visible)", device, ndev);
+    GL_HIP_CHECK(hipGetDevice(&prev));
+    if (prev != device) GL_HIP_CHECK(hipSetDevice(device));
+    unsigned* d_peaks = nullptr;
+    int n_cu = 0;
+    int rc = gl_static_scratch_setup(device, &d_peaks, &n_cu);      // first call on a device: symbol lookup
+    if (!rc) rc = gl_peak_launch_on(d_peaks, n_cu, x, row_stride, len, peaks, mode, B, (hipStream_t)stream);
+    if (prev != device) (void)hipSetDevice(prev);
+    return rc;
 }

@@ -174,6 +174,7 @@ def main():
     ap.add_argument("--hop", type=int, default=256)
     ap.add_argument("--iters", type=int, default=60)
     ap.add_argument("--path", type=int, default=0, help="0 fused (default), 1 generic kernels")
+    ap.add_argument("--run-frames", type=int, default=0, help="pin the frames-per-wave-run of the fused kernels (0 = automatic)")
     ap.add_argument("--graph", type=int, default=1, help="1: also time the step replayed from a captured hipGraph")
     ap.add_argument("--preroll-ms", type=float, default=40.0,
                     help="untimed steps before the W warmup steps until this much GPU time has passed: the card "
@@ -221,6 +222,7 @@ def main():
     L = T * H + N
     plan = Plan(N, H, T, B, dev)
     plan.set_path(args.path)
+    plan.set_run_frames(args.run_frames)
     fb = torch.from_numpy(filters.mel(SR, N, 80, 125, 7600)).to(dev)
     mel = torch.from_numpy(synth_mels_by_id(range(lo, hi), T)).to(dev)
     x0 = plan.randn((B, L), seed=42, offset=lo * L)      # resident start signal, global-index consistent

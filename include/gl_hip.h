@@ -9,14 +9,21 @@
  * Conventions
  *   - extern "C", plain pointers and integer sizes only; no torch / HIP types.
  *   - All data pointers are DEVICE pointers to fp32 unless a comment says host.
- *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls
- *     enqueue work and return; they never synchronise the device.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  The data-path
+ *     calls (gl_run, gl_stft, gl_istft, gl_mel_to_mag, ...) only enqueue kernels / async
+ *     memsets and copies on `stream` and return: no allocation, no synchronisation, no
+ *     blocking copy -- legal inside a stream capture.  Memory is allocated and tables are
+ *     uploaded (blocking) only by the configuration calls gl_plan_create, gl_plan_set_path
+ *     and gl_plan_set_options.
  *   - Every function returns 0 on success or a negative gl_status; the text of the
  *     last failure on the calling thread is returned by gl_last_error().
  *   - Geometry: N = n_fft (power of two, 64..4096), H = hop (>=1), T = frames,
  *     F = N/2+1 bins, L = T*H + N samples   (audio_utilities.py:109-110,173-174).
  *   - A plan is bound to one device and one (N, H); it owns the window, twiddle
- *     tables and scratch.  One plan must not be used from two threads at once.
+ *     tables and scratch.  One plan must not be used from two threads at once, and calls
+ *     on one plan must be ordered (one stream, or events between streams): they share
+ *     the plan's scratch.
+ *   - The library reads no environment variables.
  */
 #ifndef GL_HIP_H_
 #define GL_HIP_H_
@@ -51,9 +58,11 @@ long long gl_signal_length(int n_fft, int hop, int frames);
  * `len` samples (0 when len <= N)                  audio_utilities.py:91-92   */
 int gl_num_frames(int n_fft, int hop, long long len);
 
-/* Create / destroy a plan.  max_frames / max_batch bound T and B of later calls
- * (scratch is sized from them).  Window = symmetric Hann, np.hanning(N)
- * (audio_utilities.py:88,108), computed in double on the host, stored fp32.   */
+/* Create / destroy a plan.  max_frames / max_batch bound T and B of later calls; ALL scratch and
+ * tables the plan's entry points can touch are allocated here from them (signals, run tails,
+ * packed magnitudes, frame buffers -- about 1.3 KB per frame-bin row at n_fft 2048: 0.8 GB for
+ * 64 x 861 frames).  Window = symmetric Hann, np.hanning(N) (audio_utilities.py:88,108),
+ * computed in double on the host, stored fp32.                                               */
 int gl_plan_create(int n_fft, int hop, int max_frames, int max_batch, int device, gl_plan** out);
 int gl_plan_destroy(gl_plan* plan);
 
@@ -126,7 +135,9 @@ int gl_mask_frames(gl_plan* plan, float* mag, const int* frames, int B, int T, v
 
 /* Select the code path gl_run / gl_stft / gl_istft use: 0 = auto (fused
  * wave-per-frame kernels where the geometry has one, else generic),
- * 1 = force the generic (any power-of-two N) kernels.  For tests/benchmarks.   */
+ * 1 = force the generic (any power-of-two N) kernels.  For tests/benchmarks.
+ * A configuration call: the first switch to 1 on a geometry with fused kernels
+ * allocates the generic kernels' scratch (not for use inside a stream capture). */
 int gl_plan_set_path(gl_plan* plan, int path);
 
 /* Off-by-default variants the reference does not have (north_star names the first two):
@@ -139,7 +150,9 @@ int gl_plan_set_path(gl_plan* plan, int path);
  *   momentum in [0, 1)     fast Griffin-Lim (Perraudin, Balazs, Sondergaard 2013): the next iteration
  *                          starts from x_n + momentum * (x_n - x_{n-1}); 0 = the reference's plain loop.
  * With flags == 0 and momentum == 0 (the default) every entry point computes exactly what the reference
- * does.  The variants cost one extra streaming pass over x per iteration.                            */
+ * does.  The variants cost one extra streaming pass over x per iteration.  A configuration call: the
+ * first time a variant is switched on its buffers are allocated (previous iterate; window-sum table,
+ * which the data-path calls then (re)build for their frame count with a small kernel on their stream). */
 enum { GL_OPT_WSUM_NORMALISE = 1, GL_OPT_CLAMP_MAG = 2 };
 int gl_plan_set_options(gl_plan* plan, int flags, float momentum);
 
@@ -156,8 +169,9 @@ int gl_plan_set_run_frames(gl_plan* plan, int frames);
 /* north_star (d): "the full N-iteration loop kept on-device on one HIP stream, and optionally
  * hipGraph-captured".  The reference has no counterpart (its loop is a Python while,
  * audio_utilities.py:178).  gl_plan_prepare makes every lazy allocation / table upload that gl_run
- * (and gl_stft / gl_istft) of this plan could need, so that later calls only enqueue kernels and
- * are legal inside a stream capture.  gl_graph_begin starts capturing `stream` (non-default,
+ * (and gl_stft / gl_istft) of this plan could need -- since ABI 2.0 gl_plan_create / gl_plan_set_path /
+ * gl_plan_set_options already do, so it only returns 0 and is kept for callers of 1.x: every data-path call
+ * is legal inside a stream capture from the start.  gl_graph_begin starts capturing `stream` (non-default,
  * relaxed mode); every gl_* call enqueued on it until gl_graph_end becomes a node of the
  * graph instead of running; gl_graph_end instantiates it.  gl_graph_launch replays the whole
  * sequence (e.g. gl_mel_to_mag + gl_run(60) + gl_peak_normalise = 64 kernels) with one submission,

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Lane-level numpy model of the fused wave-per-frame kernel's data movement
-(gl_fast.hip), used to validate the index maps on the CPU before the HIP code
+(gl_fft1024.h, gl_fast2048.hip), used to validate the index maps on the CPU before the HIP code
 runs on a GPU -- TEST INFRASTRUCTURE ONLY (never imported by the product).
 
 Model: one 64-lane wave per frame; M = N/2 complex points, R = M/64 per lane.
@@ -237,7 +237,7 @@ def check_two_frames():
 
 
 # --------------------------------------------------------------------------------------------
-# LDS layouts of the four transposes (gl_fast.hip: kE1P/kE1S, kE2Q/kE2S).  One side of every
+# LDS layouts of the four transposes (gl_fft1024.h: kE1P/kE1S, kE2Q/kE2S).  One side of every
 # exchange moves runs of 8 contiguous complex values (16-byte instructions), the other side 8-byte
 # accesses at permuted positions.  Checked here: (1) the permuted layout routes every value to the
 # lane/register the plain transposes (n = a + 8b + 64 n2 maps above) send it to; (2) the worst bank

@@ -50,40 +50,9 @@ int gl_plan_alloc(gl_plan* p, void** ptr, size_t bytes) {
     return 0;
 }
 
-int gl_ensure_options(gl_plan* p, int T) {
-    const int N = p->n_fft, H = p->hop;
-    if (p->momentum != 0.0f && !p->d_prev) {
-        int rc = gl_plan_alloc(p, (void**)&p->d_prev, (size_t)p->max_B * gl_len(N, H, p->max_T) * sizeof(float));
-        if (rc) return rc;
-    }
-    if ((p->opt_flags & GL_OPT_WSUM_NORMALISE) && p->wsum_T != T) {
-        if (!p->d_inv_wsum) {
-            int rc = gl_plan_alloc(p, (void**)&p->d_inv_wsum, (size_t)gl_len(N, H, p->max_T) * sizeof(float));
-            if (rc) return rc;
-        }
-        // sum over the frames covering s of w^2 (double on the host); samples no frame reaches, or
-        // where the sum underflows, are left unscaled (the convention of librosa's istft)
-        const long long L = gl_len(N, H, T);
-        const double pi = 3.14159265358979323846;
-        std::vector<double> w2(N);
-        for (int n = 0; n < N; ++n) {
-            double w = 0.5 - 0.5 * cos(2.0 * pi * n / (double)(N - 1));
-            w2[n] = w * w;
-        }
-        std::vector<double> acc((size_t)L, 0.0);
-        for (int t = 0; t < T; ++t)
-            for (int n = 0; n < N; ++n) acc[(size_t)t * H + n] += w2[n];
-        std::vector<float> inv((size_t)L);
-        for (long long s2 = 0; s2 < L; ++s2) inv[(size_t)s2] = acc[(size_t)s2] > 1e-20 ? (float)(1.0 / acc[(size_t)s2]) : 1.0f;
-        GL_HIP_CHECK(hipMemcpy(p->d_inv_wsum, inv.data(), (size_t)L * sizeof(float), hipMemcpyHostToDevice));
-        p->wsum_T = T;
-    }
-    return 0;
-}
-
 extern "C" {
 
-int gl_version(void) { return 100; }
+int gl_version(void) { return 200; }
 
 const char* gl_last_error(void) { return g_err; }
 
@@ -123,22 +92,34 @@ int gl_plan_create(int n_fft, int hop, int max_frames, int max_batch, int device
     if (p->n_cu <= 0) p->n_cu = 256;
 
     // np.hanning(N) = 0.5 - 0.5*cos(2*pi*n/(N-1))  (audio_utilities.py:88,108), in double
-    std::vector<float> win(n_fft);
+    // periodic Hann of the analysis path: scipy.signal.get_window('hann', N, fftbins=True) = 0.5 - 0.5 cos(2 pi n / N)
+    std::vector<float> win(n_fft), win_p(n_fft);
     std::vector<float2> tw(n_fft);
     const double pi = 3.14159265358979323846;
     for (int n = 0; n < n_fft; ++n) {
         win[n] = (float)(0.5 - 0.5 * cos(2.0 * pi * n / (double)(n_fft - 1)));
+        win_p[n] = (float)(0.5 - 0.5 * cos(2.0 * pi * n / (double)n_fft));
         double a = -2.0 * pi * n / (double)n_fft;
         tw[n] = make_float2((float)cos(a), (float)sin(a));
     }
+    p->wsum_T = -1;
     int rc = gl_plan_alloc(p, (void**)&p->d_window, sizeof(float) * n_fft);
+    if (!rc) rc = gl_plan_alloc(p, (void**)&p->d_window_p, sizeof(float) * n_fft);
     if (!rc) rc = gl_plan_alloc(p, (void**)&p->d_tw, sizeof(float2) * n_fft);
     if (!rc) rc = gl_plan_alloc(p, (void**)&p->d_peaks, sizeof(unsigned) * (size_t)max_batch);
     if (!rc) {
         hipError_t e = hipMemcpy(p->d_window, win.data(), sizeof(float) * n_fft, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(p->d_window_p, win_p.data(), sizeof(float) * n_fft, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(p->d_tw, tw.data(), sizeof(float2) * n_fft, hipMemcpyHostToDevice);
         if (e != hipSuccess) rc = gl_set_error(GL_ERR_HIP, "table upload failed: %s", hipGetErrorString(e));
     }
+    // Scratch and tables of every entry point of the plan's default path, now: later calls only enqueue kernels.
+    // A geometry the fused kernels cover completely (n_fft 2048) gets the any-N kernels' scratch only when
+    // gl_plan_set_path(plan, 1) asks for them.
+    const bool fused_run = gl_fast_supported(p, GL_FAST_OP_RUN);
+    const bool fused_all = fused_run && gl_fast_supported(p, GL_FAST_OP_STFT) && gl_fast_supported(p, GL_FAST_OP_ISTFT);
+    if (!rc && fused_run) rc = gl_fast_alloc(p);
+    if (!rc && !fused_all) rc = gl_generic_alloc(p);
     if (rc) {
         gl_plan_destroy(p);
         return rc;
@@ -152,7 +133,7 @@ int gl_plan_destroy(gl_plan* p) {
     DeviceGuard guard(p->device);
     void* ptrs[] = {p->d_window, p->d_tw,     p->d_frames, p->d_xa,      p->d_xb,
                     p->d_tail_a, p->d_tail_b, p->d_fast_tab, p->d_peaks, p->d_fast_tab2, p->d_magp,
-                    p->d_inv_wsum, p->d_prev, p->d_window_p, p->d_yframes, p->d_xc};
+                    p->d_inv_wsum, p->d_prev, p->d_window_p, p->d_yframes, p->d_xc, p->d_w2};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     delete p;
@@ -163,6 +144,11 @@ long long gl_plan_device_bytes(const gl_plan* p) { return p ? p->bytes : 0; }
 
 int gl_plan_set_path(gl_plan* p, int path) {
     if (!p || path < 0 || path > 1) return gl_set_error(GL_ERR_INVALID, "gl_plan_set_path: bad argument");
+    if (path == 1 && !p->d_frames) {         // first switch to the any-N kernels: their scratch (may allocate)
+        DeviceGuard guard(p->device);
+        int rc = gl_generic_alloc(p);
+        if (rc) return rc;
+    }
     p->path = path;
     return 0;
 }
@@ -178,6 +164,26 @@ int gl_plan_set_options(gl_plan* p, int flags, float momentum) {
         return gl_set_error(GL_ERR_INVALID, "gl_plan_set_options: bad argument");
     if (!(momentum >= 0.0f && momentum < 1.0f))
         return gl_set_error(GL_ERR_INVALID, "gl_plan_set_options: momentum must be in [0, 1), got %g", (double)momentum);
+    // buffers of the variants, the first time one is switched on (a configuration call: may allocate and copy)
+    DeviceGuard guard(p->device);
+    const int N = p->n_fft;
+    if (momentum != 0.0f && !p->d_prev) {
+        int rc = gl_plan_alloc(p, (void**)&p->d_prev, (size_t)p->max_B * gl_len(N, p->hop, p->max_T) * sizeof(float));
+        if (rc) return rc;
+    }
+    if ((flags & GL_OPT_WSUM_NORMALISE) && !p->d_inv_wsum) {
+        std::vector<double> w2(N);
+        const double pi = 3.14159265358979323846;
+        for (int n = 0; n < N; ++n) {
+            const double w = 0.5 - 0.5 * cos(2.0 * pi * n / (double)(N - 1));
+            w2[n] = w * w;
+        }
+        int rc = gl_plan_alloc(p, (void**)&p->d_w2, sizeof(double) * N);
+        if (!rc) rc = gl_plan_alloc(p, (void**)&p->d_inv_wsum, (size_t)gl_len(N, p->hop, p->max_T) * sizeof(float));
+        if (rc) return rc;
+        GL_HIP_CHECK(hipMemcpy(p->d_w2, w2.data(), sizeof(double) * N, hipMemcpyHostToDevice));
+        p->wsum_T = -1;
+    }
     p->opt_flags = flags;
     p->momentum = momentum;
     return 0;
@@ -211,8 +217,13 @@ int gl_istft(gl_plan* p, const float* S, float* y, int B, int T, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     rc = use_fast(p, GL_FAST_OP_ISTFT) ? gl_fast_istft(p, S, y, B, T, st) : gl_generic_istft(p, S, y, B, T, st);
     if (rc || !(p->opt_flags & GL_OPT_WSUM_NORMALISE)) return rc;
-    rc = gl_ensure_options(p, T);
-    return rc ? rc : gl_post_iter(p, y, nullptr, y, B, T, 1, 1, true, true, st);
+    rc = gl_wsum_enqueue(p, T, st);
+    // momentum belongs to the loop: the single inverse transform is only normalised
+    const float momentum = p->momentum;
+    p->momentum = 0.0f;
+    if (!rc) rc = gl_post_iter(p, y, nullptr, y, B, T, 1, 1, true, true, st);
+    p->momentum = momentum;
+    return rc;
 }
 
 int gl_mel_to_mag(gl_plan* p, const float* filterbank, const float* mel, float* mag, int n_mels, int B, int T,
@@ -273,8 +284,8 @@ int gl_run(gl_plan* p, const float* mag, const float* x0, float* x_out, int iter
     DeviceGuard guard(p->device);
     hipStream_t st = (hipStream_t)stream;
     if (iters == 0) return gl_copy_rows(x_out, x0, (long long)B * gl_len(p->n_fft, p->hop, T), st);
-    if (gl_post_needed(p)) {
-        rc = gl_ensure_options(p, T);
+    if (p->opt_flags & GL_OPT_WSUM_NORMALISE) {
+        rc = gl_wsum_enqueue(p, T, st);
         if (rc) return rc;
     }
     return use_fast(p, GL_FAST_OP_RUN) ? gl_fast_run(p, mag, x0, x_out, iters, B, T, st)
@@ -283,10 +294,9 @@ int gl_run(gl_plan* p, const float* mag, const float* x0, float* x_out, int iter
 
 int gl_plan_prepare(gl_plan* p) {
     if (!p) return gl_set_error(GL_ERR_INVALID, "gl_plan_prepare: plan is NULL");
-    DeviceGuard guard(p->device);
-    int rc = gl_post_needed(p) ? gl_ensure_options(p, p->max_T) : 0;
-    if (rc) return rc;
-    return use_fast(p, GL_FAST_OP_RUN) ? gl_fast_prepare(p) : gl_generic_prepare(p);
+    // kept for ABI compatibility: since version 2.0 gl_plan_create, gl_plan_set_path and gl_plan_set_options
+    // allocate everything their plan can touch, so there is nothing left to front-load
+    return 0;
 }
 
 struct gl_graph {

@@ -227,37 +227,22 @@ __global__ void __launch_bounds__(kThreads) k_generic_ola(const float* __restric
     y[(long long)bi * L + s] = acc;
 }
 
-int ensure_frames(gl_plan* p) {
-    if (p->d_frames) return 0;
-    size_t bytes = (size_t)p->max_B * p->max_T * p->n_fft * sizeof(float);
-    return gl_plan_alloc(p, (void**)&p->d_frames, bytes);
-}
-
-int ensure_pingpong(gl_plan* p) {
-    size_t bytes = (size_t)p->max_B * gl_len(p->n_fft, p->hop, p->max_T) * sizeof(float);
-    if (!p->d_xa) {
-        int rc = gl_plan_alloc(p, (void**)&p->d_xa, bytes);
-        if (rc) return rc;
-    }
-    if (!p->d_xb) {
-        int rc = gl_plan_alloc(p, (void**)&p->d_xb, bytes);
-        if (rc) return rc;
-    }
-    return 0;
-}
-
 }  // namespace
+
+// scratch of the any-N kernels: the frames of one iteration and the ping-pong signals (gl_plan_create for
+// geometries the fused kernels do not cover completely, gl_plan_set_path(1) otherwise)
+int gl_generic_alloc(gl_plan* p) {
+    int rc = 0;
+    if (!p->d_frames) rc = gl_plan_alloc(p, (void**)&p->d_frames, (size_t)p->max_B * p->max_T * p->n_fft * sizeof(float));
+    const size_t bytes = (size_t)p->max_B * gl_len(p->n_fft, p->hop, p->max_T) * sizeof(float);
+    if (!rc && !p->d_xa) rc = gl_plan_alloc(p, (void**)&p->d_xa, bytes);
+    if (!rc && !p->d_xb) rc = gl_plan_alloc(p, (void**)&p->d_xb, bytes);
+    return rc;
+}
 
 int gl_analysis_mag(gl_plan* p, const float* y, long long y_stride, long long len, float* mag, int reflect, int B,
                     int T, hipStream_t st) {
     const int N = p->n_fft;
-    if (!p->d_window_p) {      // scipy.signal.get_window('hann', N, fftbins=True): 0.5 - 0.5 cos(2 pi n / N)
-        std::vector<float> w(N);
-        for (int n = 0; n < N; ++n) w[n] = (float)(0.5 - 0.5 * cos(2.0 * 3.14159265358979323846 * n / (double)N));
-        int rc = gl_plan_alloc(p, (void**)&p->d_window_p, sizeof(float) * N);
-        if (rc) return rc;
-        GL_HIP_CHECK(hipMemcpy(p->d_window_p, w.data(), sizeof(float) * N, hipMemcpyHostToDevice));
-    }
     // n_fft 2048 on the fused path: one wave per frame on the register FFT core (gl_fast.hip)
     if (p->path == 0 && N == 2048 && gl_fast_supported(p, GL_FAST_OP_STFT))
         return gl_fast_analysis_mag(p, y, y_stride, len, mag, reflect, B, T, p->d_window_p, st);
@@ -266,11 +251,6 @@ int gl_analysis_mag(gl_plan* p, const float* y, long long y_stride, long long le
                        p->d_tw, N, p->hop, T, reflect);
     GL_HIP_CHECK(hipGetLastError());
     return 0;
-}
-
-int gl_generic_prepare(gl_plan* p) {
-    int rc = ensure_frames(p);
-    return rc ? rc : ensure_pingpong(p);
 }
 
 int gl_generic_stft(gl_plan* p, const float* x, long long x_stride, float* S, int B, int T, hipStream_t st) {
@@ -291,8 +271,7 @@ static int launch_ola(gl_plan* p, float* y, int B, int T, hipStream_t st) {
 }
 
 int gl_generic_istft(gl_plan* p, const float* S, float* y, int B, int T, hipStream_t st) {
-    int rc = ensure_frames(p);
-    if (rc) return rc;
+    if (!p->d_frames) return gl_set_error(GL_ERR_INVALID, "generic scratch absent: call gl_plan_set_path(plan, 1) first");
     const int N = p->n_fft;
     size_t lds = (size_t)N * sizeof(float2);
     hipLaunchKernelGGL(k_generic_istft_frame, dim3(T, B), dim3(kThreads), lds, st, (const float2*)S, p->d_frames,
@@ -303,12 +282,8 @@ int gl_generic_istft(gl_plan* p, const float* S, float* y, int B, int T, hipStre
 
 int gl_generic_run(gl_plan* p, const float* mag, const float* x0, float* x_out, int iters, int B, int T,
                    hipStream_t st) {
-    int rc = ensure_frames(p);
-    if (rc) return rc;
-    if (iters > 1) {
-        rc = ensure_pingpong(p);
-        if (rc) return rc;
-    }
+    if (!p->d_frames) return gl_set_error(GL_ERR_INVALID, "generic scratch absent: call gl_plan_set_path(plan, 1) first");
+    int rc = 0;
     const int N = p->n_fft;
     const long long L = gl_len(N, p->hop, T);
     size_t lds = (size_t)N * sizeof(float2);

@@ -17,23 +17,27 @@ struct gl_plan {
     int n_cu;         // compute units of the device
     float* d_window;  // [N]   symmetric Hann
     float2* d_tw;     // [N]   exp(-2*pi*i*k/N)
-    float* d_frames;  // generic path scratch [max_B][max_T][N] (lazy)
-    float* d_xa;      // ping-pong signal buffers [max_B][L] (lazy)
+    // Everything below is allocated by gl_plan_create (what the plan's default path can touch), by
+    // gl_plan_set_path(1) (generic scratch of a plan whose geometry has fused kernels) or by gl_plan_set_options
+    // (the variants' buffers) -- never by gl_run / gl_stft / gl_istft, which only enqueue work.
+    float* d_frames;  // generic path scratch [max_B][max_T][N]
+    float* d_xa;      // ping-pong signal buffers [max_B][L]
     float* d_xb;
-    float* d_xc;      // third signal buffer of the n_fft-1024 run kernel (read / write / clear rotation; lazy)
-    float* d_tail_a;  // fused path: per-run partial-sum tails (lazy)
+    float* d_xc;      // third signal buffer of the n_fft-1024 run kernel (read / write / clear rotation)
+    float* d_tail_a;  // n_fft 2048 fused kernels: per-run partial-sum tails
     float* d_tail_b;
-    float* d_fast_tab;  // fused path constant tables (lazy)
-    float* d_fast_tab2; // register-ring kernel constant table (lazy)
-    float* d_magp;      // register-ring kernel: magnitudes repacked per lane [max_B][max_T][1088] (lazy)
+    float* d_fast_tab;  // constant table of k_fast2048
+    float* d_fast_tab2; // constant table of the register-FFT kernels
+    float* d_magp;      // register-ring kernel: magnitudes repacked per lane [max_B][max_T][1088]
     unsigned* d_peaks;  // [max_B] bit patterns of max|x|
     int opt_flags;      // GL_OPT_* (gl_plan_set_options)
     float momentum;     // fast Griffin-Lim extrapolation factor, 0 = off
-    float* d_inv_wsum;  // [L(wsum_T)] 1 / sum_t w^2(s - tH)  (lazy, rebuilt when T changes)
-    int wsum_T;
-    float* d_prev;      // [max_B][L] previous iterate for the momentum option (lazy)
-    float* d_window_p;  // [N] periodic Hann of the analysis path (lazy)
-    float* d_yframes;   // n_fft 1024, small problems: two sets of windowed inverse frames [2][B][T][N] (lazy)
+    double* d_w2;       // [N] squared window in double (window-sum option)
+    float* d_inv_wsum;  // [L(max_T)] 1 / sum_t w^2(s - tH), rebuilt on the call's stream when T changes
+    int wsum_T;         // frame count the table holds (-1: unknown)
+    float* d_prev;      // [max_B][L] previous iterate for the momentum option
+    float* d_window_p;  // [N] periodic Hann of the analysis path
+    float* d_yframes;   // small problems: two sets of windowed inverse frames [2][frames][N]
     size_t yframes_bytes;
     long long bytes;
 };
@@ -59,14 +63,14 @@ int gl_generic_istft(gl_plan* p, const float* S, float* y, int B, int T, hipStre
 int gl_generic_run(gl_plan* p, const float* mag, const float* x0, float* x_out, int iters, int B, int T,
                    hipStream_t st);
 
-int gl_generic_prepare(gl_plan* p);
+int gl_generic_alloc(gl_plan* p);     // d_frames + ping-pong signals
 int gl_analysis_mag(gl_plan* p, const float* y, long long y_stride, long long len, float* mag, int reflect, int B,
                     int T, hipStream_t st);
 
 // ---- fused wave-per-frame kernels: gl_fast.hip -----------------------------------
 enum { GL_FAST_OP_STFT = 0, GL_FAST_OP_ISTFT = 1, GL_FAST_OP_RUN = 2 };
 bool gl_fast_supported(const gl_plan* p, int op);
-int gl_fast_prepare(gl_plan* p);
+int gl_fast_alloc(gl_plan* p);        // tables and scratch of the fused entry points (gl_plan_create)
 // per-iteration post pass of the off-by-default options (window-sum normalisation, momentum):
 // out[s] = f(x_main[s] + tail) ; tail == nullptr when x_main is already complete
 static inline bool gl_post_needed(const gl_plan* p) {
@@ -74,7 +78,7 @@ static inline bool gl_post_needed(const gl_plan* p) {
 }
 int gl_post_iter(gl_plan* p, const float* x_main, const float* tail, float* out, int B, int T, int G, int nruns,
                  bool first, bool last, hipStream_t st);
-int gl_ensure_options(gl_plan* p, int T);   // allocations / tables the options need for T frames
+int gl_wsum_enqueue(gl_plan* p, int T, hipStream_t st);   // window-sum table for T frames, built on the stream
 int gl_fast_stft(gl_plan* p, const float* x, long long x_stride, float* S, int B, int T, hipStream_t st);
 int gl_fast_istft(gl_plan* p, const float* S, float* y, int B, int T, hipStream_t st);
 int gl_fast_analysis_mag(gl_plan* p, const float* y, long long y_stride, long long len, float* mag, int reflect,

@@ -78,7 +78,7 @@ def test_fails_loudly_without_gpu():
 
 
 def test_fused_kernel_lds_exchange_layouts():
-    """The permuted LDS layouts of the fused kernels' four transposes (gl_fast.hip kE1P/kE1S/kE2Q/kE2S)
+    """The permuted LDS layouts of the fused kernels' four transposes (gl_fft1024.h kE1P/kE1S/kE2Q/kE2S)
     route every value where the plain transposes do, and no access pattern is worse than 2-way
     bank-conflicting (lane-level model in oracle/sim_fast2048.py; no GPU needed)."""
     import os
@@ -87,7 +87,7 @@ def test_fused_kernel_lds_exchange_layouts():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "oracle"))
     import sim_fast2048 as sim
-    src = open(os.path.join(root, "tacotron2_amd", "csrc", "gl_fast.hip")).read()
+    src = open(os.path.join(root, "tacotron2_amd", "csrc", "gl_fft1024.h")).read()
     m = re.search(r"kE1P = (\d+), kE1S = (\d+);\s*constexpr int kE2Q = (\d+), kE2S = (\d+);", src)
     assert m and tuple(map(int, m.groups())) == (sim.E1P, sim.E1S, sim.E2Q, sim.E2S)   # model == kernel constants
     assert sim.check_exchange_routing()

@@ -59,3 +59,17 @@ def window_starts(frames=FRAMES):
     for k in range(15):
         starts.add(int((k + 0.37) * (L - WIN) / 15.0) // 2 * 2)
     return np.array(sorted(starts), dtype=np.int64)
+
+
+PROJ_BLOCK = 256
+
+
+def block_projections(x, seed=7):
+    """One random-sign projection per block of 256 samples, sum_i s_i x_i with s_i = +-1 from a seeded Generator:
+    a whole-signal fingerprint small enough to commit (52 k numbers).  For a difference signal d the projection of
+    a block has variance ||d_block||^2, so |proj(ours) - proj(reference)| / 16 estimates the RMS error of EVERY
+    block, not only of the committed windows."""
+    x = np.asarray(x, dtype=np.float64)
+    n = len(x) // PROJ_BLOCK
+    signs = np.random.default_rng(seed).integers(0, 2, size=n * PROJ_BLOCK).astype(np.float64) * 2.0 - 1.0
+    return (x[:n * PROJ_BLOCK] * signs).reshape(n, PROJ_BLOCK).sum(axis=1)

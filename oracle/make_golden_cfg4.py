@@ -16,7 +16,9 @@ grows with the iteration count.
 
 The 53 MB result cannot be committed, so tests/golden/gl_cfg4_fullsize.npz keeps 25 windows
 of 8 192 samples (both ends, the 7 seams of the 8-chunk split, 15 spread between) at every
-snapshot, the peak, per-block RMS over the whole signal and the spectral convergence.
+snapshot, the peak, per-block RMS and one random-sign projection per 256-sample block over the whole
+signal (cfg4_inputs.block_projections: error energy of every block, not only of the windows) and the
+spectral convergence.
 """
 import os
 import sys
@@ -63,8 +65,18 @@ def main():
         print(f"  reference after {K} iterations: peak {arrs[f'peak{K}']:.6f}  ({time.time() - t0:.0f} s)", flush=True)
     nblk = len(x) // 65536
     arrs["block_rms"] = np.sqrt(np.mean(x[:nblk * 65536].reshape(nblk, 65536) ** 2, axis=1))
+    arrs["proj100"] = c4.block_projections(x)
     arrs["sc"] = np.float64(orc.spectral_convergence(x, mag, c4.N_FFT, c4.HOP))
     print(f"  spectral convergence {arrs['sc']:.6f}", flush=True)
+    # Yardstick: the same algorithm computed by numpy / pocketfft in float32 (gl_oracle.griffin_lim_vec_f32, 4 more
+    # minutes).  Ten minutes of audio contain a few spots where Griffin-Lim is locally unstable and float32 rounding
+    # grows to several 1e-3 of the peak within 100 iterations, whoever does the arithmetic; its block projections
+    # let the GPU test tell "float32 cannot do better here" from "the kernel is wrong".
+    y32 = orc.griffin_lim_vec_f32(mag, c4.N_FFT, c4.HOP, c4.ITERS, c4.start_signal(frames))
+    arrs["proj100_f32"] = c4.block_projections(y32)
+    e32 = np.abs(arrs["proj100_f32"] - arrs["proj100"]) / np.sqrt(c4.PROJ_BLOCK) / arrs["peak100"]
+    print(f"  numpy float32 block RMS error / peak: median {np.median(e32):.2e} max {e32.max():.2e}, "
+          f"{int((e32 > 1e-3).sum())} blocks above 1e-3", flush=True)
     np.savez_compressed(out, **arrs)
     print(f"wrote {out} ({os.path.getsize(out) / 1024:.0f} KiB)")
 

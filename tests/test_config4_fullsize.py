@@ -5,10 +5,10 @@ tests/golden/gl_cfg4_fullsize.npz was produced by the REAL reference (oracle/mak
 /root/reference/audio_utilities.py and runs reconstruct_signal_griffin_lim, lines 154-188, on the seeded input
 of oracle/cfg4_inputs.py).  The 53 MB result is kept as 25 windows of 8 192 samples -- both ends, the seven
 seams of the 8-chunk split, 15 spread between -- after 10, 25, 50 and 100 iterations, plus the peak, the
-spectral convergence and per-block RMS of the whole signal.  Here the same input is regenerated and run
+spectral convergence, and per-block RMS plus one random-sign projection per 256 samples of the whole signal.  Here the same input is regenerated and run
 (i) in one piece and (ii) as 8 frame chunks with the exact halo schedule (refresh every 10 iterations), and
 both are held to the north-star tolerance against the fixture: max-abs error <= 1e-3 of the peak on every
-window and spectral-convergence delta <= 1e-3.
+window, spectral-convergence delta <= 1e-3, and the per-block error bound of check_every_block over the whole signal.
 """
 import os
 
@@ -49,6 +49,32 @@ def window_error(y, d, K):
     return float(err.max() / float(d[f"peak{K}"])), err.max(axis=1) / float(d[f"peak{K}"])
 
 
+def check_every_block(y, d, what):
+    """Every block of the signal, not only the windows: one random-sign projection per 256 samples estimates the
+    block's RMS error against the reference (|difference| / 16).
+
+    Ten minutes of audio contain a few spots where Griffin-Lim is locally unstable: float32 rounding grows there to
+    several 1e-3 of the peak within 100 iterations WHOEVER does the arithmetic -- numpy's own float32 run of the
+    reference algorithm (`proj100_f32`, oracle/gl_oracle.griffin_lim_vec_f32) has 13 of 51 688 blocks above 1e-3 and
+    a worst block at 6.1e-3; the HIP kernels measured 14 blocks and 5.8e-3.  So the bound that is
+    true: 99.9 % of the blocks within 1e-3 (measured 1.6e-4), every block above 1e-3 next to a spot where the
+    float32 numpy run degrades as well, no more such blocks than twice numpy's, none worse than twice its worst."""
+    peak = float(d["peak100"])
+    e = np.abs(c4.block_projections(y) - d["proj100"]) / np.sqrt(c4.PROJ_BLOCK) / peak
+    e32 = np.abs(d["proj100_f32"] - d["proj100"]) / np.sqrt(c4.PROJ_BLOCK) / peak
+    bad, bad32 = np.flatnonzero(e > TOL), np.flatnonzero(e32 > 1e-4)
+    print("%s: block RMS error / peak from the projections: median %.2e p99 %.2e p99.9 %.2e max %.2e, %d blocks above "
+          "1e-3 (numpy float32: median %.2e p99.9 %.2e max %.2e, %d blocks)" % (
+              what, np.median(e), np.quantile(e, 0.99), np.quantile(e, 0.999), e.max(), len(bad),
+              np.median(e32), np.quantile(e32, 0.999), e32.max(), int((e32 > TOL).sum())))
+    assert np.quantile(e, 0.999) <= TOL
+    assert np.median(e) <= 1e-5
+    assert len(bad) <= 2 * int((e32 > TOL).sum()) + 2
+    assert e.max() <= 2.0 * e32.max()
+    for blk in bad:                 # an unstable spot of the trajectory, not of the implementation
+        assert np.min(np.abs(bad32 - blk)) <= 64, "block %d is off by %.2e where float32 numpy is fine" % (blk, e[blk])
+
+
 def test_config4_single_piece_against_reference(cfg4):
     d, mag, mag_t, x0_t = cfg4
     grow = {}
@@ -66,6 +92,7 @@ def test_config4_single_piece_against_reference(cfg4):
     nblk = len(y) // 65536
     rms = np.sqrt(np.mean(y[:nblk * 65536].astype(np.float64).reshape(nblk, 65536) ** 2, axis=1))
     assert np.max(np.abs(rms / d["block_rms"] - 1.0)) <= TOL
+    check_every_block(y, d, "single piece")
     sc = orc.spectral_convergence(y.astype(np.float64), mag, c4.N_FFT, c4.HOP)
     print("spectral convergence: ours %.6f reference %.6f" % (sc, float(d["sc"])))
     assert abs(sc - float(d["sc"])) <= TOL_SC
@@ -84,6 +111,7 @@ def test_config4_eight_chunks_exact_schedule_against_reference(cfg4):
     print("config 4, 8 chunks, max error / peak vs the reference: %.3e (seam windows %.3e)" % (
         worst, max(per_window[i] for i, s in enumerate(d["starts"]) if (s + c4.WIN // 2) % c4.HOP == 0 and s > 0)))
     assert worst <= TOL
+    check_every_block(y, d, "8 chunks")
     sc = orc.spectral_convergence(y.astype(np.float64), mag, c4.N_FFT, c4.HOP)
     assert abs(sc - float(d["sc"])) <= TOL_SC
     # pinned run length: the chunked result is bit-identical to the single piece (same sums in the same order)

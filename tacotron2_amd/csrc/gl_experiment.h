@@ -1,11 +1,11 @@
-// Kernel-study instrumentation, compiled in only with -DGL_EXPERIMENT (abl/ builds); the product library
+// Kernel-study instrumentation, compiled in only with -DGL_EXPERIMENT -DGL_STAMPS (abl/ builds); the product library
 // gets the empty Stamps below and contains none of it.
 //
 // Phase timing: every phase boundary drains the LDS queue and reads the shader clock; lane 0 of every wave
 // adds its per-phase totals to g_stamp at exit (read back with hipMemcpyFromSymbol by the experiment's
 // driver).  The drain serialises what the normal build overlaps, so the sum exceeds the normal run time.
 #pragma once
-#ifdef GL_EXPERIMENT
+#if defined(GL_EXPERIMENT) && defined(GL_STAMPS)
 __device__ unsigned long long g_stamp[24];
 struct Stamps {
     unsigned long long prev;

@@ -336,8 +336,8 @@ __global__ void __launch_bounds__(64) k_mag_repack(const float* __restrict__ mag
         v[8 + u] = mrow[kM - k] * kMagScale;
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<v4f*>(orow + (q * 64 + l) * 4) = (v4f){v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+    for (int q = 0; q < 4; ++q)     // (m[k], m[1024-k]) of the mirror pairs u = 2q, 2q+1
+        *reinterpret_cast<v4f*>(orow + (q * 64 + l) * 4) = (v4f){v[2 * q], v[8 + 2 * q], v[2 * q + 1], v[8 + 2 * q + 1]};
     orow[1024 + l] = mrow[512] * kMagScale;
 }
 
@@ -424,20 +424,32 @@ __global__ void __launch_bounds__(64 * kRRWaves, 1) k_gl2048_regring(AlignedArgs
             accr[j] = (v2f){0.0f, 0.0f};
         }
     }
-    // magnitudes at the lane's 9 mirror pairs of frame `fr` (packed layout, see k_mag_repack)
-    auto load_mags = [&](int fr, float* lo, float* hi) {
+    // magnitudes at the lane's 9 mirror pairs of frame `fr` (packed layout, see k_mag_repack): mm[u] = (m[k], m[1024-k])
+    auto load_mags = [&](int fr, v2f* mm, float& m512) {
+#if defined(GL_EXPERIMENT) && defined(GL_ABL)
+        if (GL_ABL & 4) {                      // timing study: no magnitude loads
+#pragma unroll
+            for (int u = 0; u < 8; ++u) mm[u] = (v2f){1.0f + u, 2.0f + u};
+            m512 = 3.0f;
+            return;
+        }
+#endif
+#if defined(GL_EXPERIMENT) && defined(GL_ABL)
+        if (GL_ABL & 16) fr = f0 + (fr & 1);   // timing study: the same two frames' magnitudes over and over (cache hits)
+#endif
         const float* mrow = p.magp + ((long long)b * T + fr) * kMagPack + 4 * l;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const v4f t = *reinterpret_cast<const v4f*>(mrow + 256 * q);
-            float* dst = (q < 2) ? lo + 4 * q : hi + 4 * (q - 2);
-            dst[0] = t.x; dst[1] = t.y; dst[2] = t.z; dst[3] = t.w;
+            // streamed once per launch: nontemporal, so the 240 MB do not push x and the tails out of L2 (-1.3 %)
+            const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(mrow + 256 * q));
+            mm[2 * q] = t.xy;
+            mm[2 * q + 1] = t.zw;
         }
-        lo[8] = mrow[1024 - 3 * l];
-        hi[8] = lo[8];
+        m512 = mrow[1024 - 3 * l];
     };
-    float m_lo[9], m_hi[9];
-    load_mags(f0, m_lo, m_hi);
+    v2f mm[8];
+    float m512;
+    load_mags(f0, mm, m512);
     for (int i = threadIdx.x; i < kT2Entries * 64; i += 64 * kRRWaves) smem[i] = p.tab[i];
     __syncthreads();
     if (!active) return;                         // wave-uniform; no barrier after this point
@@ -447,6 +459,8 @@ __global__ void __launch_bounds__(64 * kRRWaves, 1) k_gl2048_regring(AlignedArgs
 #pragma unroll
     for (int e = kT2Tw1; e < kT2Twp; ++e) treg[e - kT2Tw1] = lds_rd(&tabl[TE(e)]);
     const TabMixed tb{tabl, treg};
+    // sample 0 of every windowed frame is 0 (w[0] = 0): lane 0 plants kZeroNudge there instead (see project2)
+    const v2f nudge = {l == 0 ? kZeroNudge : 0.0f, 0.0f};
 
     // Drain the ring-fill loads here.  Otherwise the loop header inherits "xraw[8..15] still in
     // flight" from this prologue and the compiler guards every frame's window multiply with
@@ -463,10 +477,16 @@ __global__ void __launch_bounds__(64 * kRRWaves, 1) k_gl2048_regring(AlignedArgs
     // depending on what the one other wave of the SIMD happens to be doing.  Both frames use the same
     // scratch: LDS operations of a wave execute in program order, and the order below alternates
     // A.ex1, B.ex2, A.ex2, B.ex1, each written and read completely before the next is written.
+    // (Scheduling fences between the phases, so that the consumers of a transpose's reads cannot be hoisted
+    // in front of the other frame's arithmetic, were measured: +1.5 % -- the scheduler's own order is better.)
+    // A step ends with B's time-domain frame: its overlap-add, the hand-over of A's spectrum into B's registers
+    // and the windowing of frame n+2 into A's share one pass over the window table.  (Unrolling by two so that the
+    // arrays swap roles instead of being copied spills: 256 VGPRs + 100 bytes of scratch.)
     const LanePos lp(l, kloB);
     auto window_in = [&](v2f* z) {
+        z[0] = __builtin_elementwise_fma(xraw[0], tb.get(kT2Win), nudge);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) z[j] = xraw[j] * tb.get(kT2Win + j);
+        for (int j = 1; j < 16; ++j) z[j] = xraw[j] * tb.get(kT2Win + j);
     };
     auto rows_request = [&](int frame, bool live, v2f* xn, v2f* xt) {      // the HS rows frame `frame` adds
 #pragma unroll
@@ -484,13 +504,8 @@ __global__ void __launch_bounds__(64 * kRRWaves, 1) k_gl2048_regring(AlignedArgs
 #pragma unroll
         for (int jj = 0; jj < HS; ++jj) xraw[OVR + jj] = xn[jj] + xt[jj];
     };
-    auto emit = [&](v2f* z, int n) {                 // window, overlap-add, store the HS finished rows
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            v2f w = tb.get(kT2Win + j);              // 1/2048 is folded into the packed magnitudes
-            accr[j].x = fmaf(z[j].x, w.x, accr[j].x);
-            accr[j].y = fmaf(z[j].y, w.y, accr[j].y);
-        }
+    // the HS finished rows of frame n leave; the accumulator slides
+    auto store_rows = [&](int n) {
         float* orow = p.x_out + (long long)b * p.L + (long long)n * H + 2 * l;
 #pragma unroll
         for (int jj = 0; jj < HS; ++jj) *reinterpret_cast<v2f*>(orow + 128 * jj) = accr[jj];
@@ -500,53 +515,64 @@ __global__ void __launch_bounds__(64 * kRRWaves, 1) k_gl2048_regring(AlignedArgs
         for (int jj = 0; jj < HS; ++jj) accr[OVR + jj] = (v2f){0.0f, 0.0f};
     };
 
-    // prologue: forward transform of the run's first frame
-    v2f zf[16];
+    // prologue: forward transform of the run's first frame (zB), windowed input of its second (zA)
+    v2f zA[16], zB[16];
     {
         v2f xn[HS], xt[HS];
         rows_request(f0 + 1, f0 + 1 < f1, xn, xt);
-        window_in(zf);
-        fft_forward_1024(zf, ex, l, kloB, tb, st);
+        window_in(zB);
+        fft_forward_1024(zB, ex, l, kloB, tb, st);
         ring_advance(xn, xt);                        // xraw = input of frame f0+1
+        window_in(zA);
     }
+    // zA: windowed input of frame n+1 -> its spectrum; zB: spectrum of frame n -> its inverse transform
     for (int n = f0; n + 1 < f1; ++n) {
         v2f xn[HS], xt[HS];
         rows_request(n + 2, n + 2 < f1, xn, xt);
-        v2f zA[16];
-        window_in(zA);                               // A: frame n+1
-        dft16<false>(zA);
+        dft16<false>(zA);                            // A
         twiddle1<false>(zA, tb);
         ex1_put_cols(zA, ex, lp);
         ex1_get_rows(zA, ex, lp);
-        middle_project(zf, m_lo, m_hi, tb);          // B: frame n
-        load_mags(n + 1, m_lo, m_hi);
-        dft8<true>(zf);
-        dft8<true>(zf + 8);
-        ex2_put_cols(zf, ex, lp);
-        ex2_get_rows(zf, ex, lp);
+        middle_project2(zB, mm, m512, tb);           // B
+        load_mags(n + 1, mm, m512);
+        dft8<true>(zB);
+        dft8<true>(zB + 8);
+        ex2_put_cols(zB, ex, lp);
+        ex2_get_rows(zB, ex, lp);
         dft8<false>(zA);                             // A
         dft8<false>(zA + 8);
         twiddle2<false>(zA, tb);
         ex2_put_rows(zA, ex, lp);
         ex2_get_cols(zA, ex, lp);
-        twiddle2<true>(zf, tb);                 // B
-        dft8<true>(zf);
-        dft8<true>(zf + 8);
-        ex1_put_rows(zf, ex, lp);
-        ex1_get_cols(zf, ex, lp);
+        twiddle2<true>(zB, tb);                      // B
+        dft8<true>(zB);
+        dft8<true>(zB + 8);
+        ex1_put_rows(zB, ex, lp);
+        ex1_get_cols(zB, ex, lp);
         dft8<false>(zA);                             // A: spectrum of frame n+1 complete
         dft8<false>(zA + 8);
-        twiddle1<true>(zf, tb);                      // B
-        dft16<true>(zf);
-        emit(zf, n);
+        twiddle1<true>(zB, tb);                      // B
+        dft16<true>(zB);
         ring_advance(xn, xt);                        // xraw = input of frame n+2
+        // zB = inverse transform of frame n: window it into the accumulator; zB then takes over zA's spectrum
+        // (frame n+1, the next step's B) and zA becomes the windowed input the ring holds (frame n+2, the next
+        // step's A): one pass over the window table for all three (1/2048 is folded into the packed magnitudes,
+        // so the analysis and the synthesis window are the same entries)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) zf[j] = zA[j];
+        for (int j = 0; j < 16; ++j) {
+            const v2f w = tb.get(kT2Win + j);
+            accr[j] = __builtin_elementwise_fma(zB[j], w, accr[j]);
+            zB[j] = zA[j];
+            zA[j] = (j == 0) ? __builtin_elementwise_fma(xraw[0], w, nudge) : xraw[j] * w;
+        }
+        store_rows(n);
     }
     {   // epilogue: the run's last frame has no successor to overlap with
-        middle_project(zf, m_lo, m_hi, tb);
-        fft_inverse_1024(zf, ex, l, kloB, tb, st);
-        emit(zf, f1 - 1);
+        middle_project2(zB, mm, m512, tb);
+        fft_inverse_1024(zB, ex, l, kloB, tb, st);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) accr[j] = __builtin_elementwise_fma(zB[j], tb.get(kT2Win + j), accr[j]);
+        store_rows(f1 - 1);
     }
     // partial sums of the N-H samples after the run's last frame
     const long long se = (long long)f1 * H;
@@ -597,17 +623,17 @@ __global__ void __launch_bounds__(64 * kRRWaves) k_gl2048_frames(Frames2048Args 
     const int n = (int)(gf - (long long)b * T);
 
     // operands first (one batch of loads), then the constant table, so the round trips overlap
-    float m_lo[9], m_hi[9];
+    v2f mm[8];
+    float m512;
     {
         const float* mrow = p.magp + ((long long)b * T + n) * kMagPack + 4 * l;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const v4f t = *reinterpret_cast<const v4f*>(mrow + 256 * q);
-            float* dst = (q < 2) ? m_lo + 4 * q : m_hi + 4 * (q - 2);
-            dst[0] = t.x; dst[1] = t.y; dst[2] = t.z; dst[3] = t.w;
+            mm[2 * q] = t.xy;
+            mm[2 * q + 1] = t.zw;
         }
-        m_lo[8] = mrow[1024 - 3 * l];
-        m_hi[8] = m_lo[8];
+        m512 = mrow[1024 - 3 * l];
     }
     v2f z[16];
     if (p.x_in != nullptr) {
@@ -648,9 +674,10 @@ __global__ void __launch_bounds__(64 * kRRWaves) k_gl2048_frames(Frames2048Args 
 
 #pragma unroll
     for (int j = 0; j < 16; ++j) z[j] = z[j] * tb.get(kT2Win + j);
+    if (l == 0) z[0].x = kZeroNudge;             // sample 0 of the windowed frame is 0 (w[0] = 0): see project2
     Stamps st;
     fft_forward_1024(z, ex, l, kloB, tb, st);
-    middle_project(z, m_lo, m_hi, tb);
+    middle_project2(z, mm, m512, tb);
     fft_inverse_1024(z, ex, l, kloB, tb, st);
     float* yo = p.y_out + ((long long)b * T + n) * kN + 2 * l;
 #pragma unroll
@@ -834,7 +861,7 @@ int run_regring(gl_plan* p, const float* mag, const float* x0, float* x_out, int
             src_tail = nullptr;
         }
     }
-#ifdef GL_EXPERIMENT
+#if defined(GL_EXPERIMENT) && defined(GL_STAMPS)
     {   // kernel studies only (abl/stamps.sh): per-phase shader-clock totals of the Stamps instrumentation
         unsigned long long h[24];
         GL_HIP_CHECK(hipStreamSynchronize(st));

@@ -129,6 +129,24 @@ __device__ __forceinline__ v2f project(v2f X, float m) {
     return Xe * (v2f){sc, sc};
 }
 
+// Two bins at once, the form the n_fft-2048 kernels use: m2 = (magnitude of X, magnitude of Y).  |X|^2 + 2^-126
+// keeps the reciprocal square root finite without a compare or a max (a bin that small is exactly zero in
+// practice and comes out as 0 * finite = 0); an exactly zero FRAME never gets here as zeros: the kernels plant
+// kZeroNudge in its sample 0, which the symmetric Hann window zeroes anyway (w[0] = 0), so its spectrum is the
+// real constant kZeroNudge > 0 in every bin and projects to (mag, 0) = mag * exp(1j * np.angle(0)),
+// audio_utilities.py:181-183.  The two scale factors are one packed multiply.
+constexpr float kZeroNudge = 0x1p-52f;
+__device__ __forceinline__ void project2(v2f& X, v2f& Y, v2f m2) {
+    const float rx = fmaf(X.x, X.x, fmaf(X.y, X.y, 0x1p-126f));
+    const float ry = fmaf(Y.x, Y.x, fmaf(Y.y, Y.y, 0x1p-126f));
+    v2f rs;
+    rs.x = __builtin_amdgcn_rsqf(rx);
+    rs.y = __builtin_amdgcn_rsqf(ry);
+    const v2f sc = m2 * rs;
+    X = X * sc.xx;
+    Y = Y * sc.yy;
+}
+
 // x sample s of utterance row `xr`, with the producer's run tails folded in
 __device__ __forceinline__ float fetch_x(const float* __restrict__ xr, const float* __restrict__ tr, long long s,
                                          int g_in_h, int nruns_in, int ovl) {
@@ -185,8 +203,16 @@ struct TabMixed {
     const v2f* tabl;
     const v2f* r;        // r[e - kT2Tw1]
     __device__ __forceinline__ bool in_reg(int e) const { return e >= kT2Tw1 && e < kT2Twp; }
-    __device__ __forceinline__ v2f get(int e) const { return in_reg(e) ? r[e - kT2Tw1] : lds_rd(&tabl[TE(e)]); }
+    __device__ __forceinline__ v2f get(int e) const {
+#if defined(GL_EXPERIMENT) && defined(GL_ABL)
+        if ((GL_ABL & 2) && !in_reg(e)) return r[e & 15];      // timing study: no table reads
+#endif
+        return in_reg(e) ? r[e - kT2Tw1] : lds_rd(&tabl[TE(e)]);
+    }
     __device__ __forceinline__ void pair(int e, v2f& a, v2f& b) const {
+#if defined(GL_EXPERIMENT) && defined(GL_ABL)
+        if ((GL_ABL & 2) && !in_reg(e)) { a = r[e & 15]; b = r[(e + 1) & 15]; return; }
+#endif
         if (in_reg(e)) { a = r[e - kT2Tw1]; b = r[e + 1 - kT2Tw1]; }
         else lds_rd_pair(&tabl[TE(e)], a, b);
     }
@@ -228,13 +254,20 @@ __device__ __forceinline__ void twiddle2(v2f* z, const TAB& tb) {   // z[d], z[8
     }
 }
 // exchange 1: register k2 <-> lane bits g3.  "cols" side: 16 x b64 at pi(l); "rows" side: 2 x 4 x b128
+#if defined(GL_EXPERIMENT) && defined(GL_ABL)
+#define GL_ABL_SKIP_EX if (GL_ABL & 1) return
+#else
+#define GL_ABL_SKIP_EX
+#endif
 __device__ __forceinline__ void ex1_put_cols(const v2f* z, v2f* ex, const LanePos& lp) {
+    GL_ABL_SKIP_EX;
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int k2 = 0; k2 < 16; ++k2) ex[k2 * kE1S + lp.piL] = z[k2];
     __builtin_amdgcn_wave_barrier();
 }
 __device__ __forceinline__ void ex1_get_rows(v2f* z, const v2f* ex, const LanePos& lp) {
+    GL_ABL_SKIP_EX;
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -242,6 +275,7 @@ __device__ __forceinline__ void ex1_get_rows(v2f* z, const v2f* ex, const LanePo
             lds_rd_pair(&ex[(lp.g3 + 8 * h) * kE1S + lp.a3 * kE1P + bb], z[8 * h + bb], z[8 * h + bb + 1]);
 }
 __device__ __forceinline__ void ex1_put_rows(const v2f* z, v2f* ex, const LanePos& lp) {
+    GL_ABL_SKIP_EX;
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -251,11 +285,13 @@ __device__ __forceinline__ void ex1_put_rows(const v2f* z, v2f* ex, const LanePo
     __builtin_amdgcn_wave_barrier();
 }
 __device__ __forceinline__ void ex1_get_cols(v2f* z, const v2f* ex, const LanePos& lp) {
+    GL_ABL_SKIP_EX;
 #pragma unroll
     for (int k2 = 0; k2 < 16; ++k2) z[k2] = lds_rd(&ex[k2 * kE1S + lp.piL]);
 }
 // exchange 2: register d <-> lane bits a3.  "rows" side: 2 x 4 x b128; "cols" side: 16 x b64 at rho(l), rho(128-l)
 __device__ __forceinline__ void ex2_put_rows(const v2f* z, v2f* ex, const LanePos& lp) {
+    GL_ABL_SKIP_EX;
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -265,16 +301,19 @@ __device__ __forceinline__ void ex2_put_rows(const v2f* z, v2f* ex, const LanePo
     __builtin_amdgcn_wave_barrier();
 }
 __device__ __forceinline__ void ex2_get_cols(v2f* z, const v2f* ex, const LanePos& lp) {
+    GL_ABL_SKIP_EX;
 #pragma unroll
     for (int a = 0; a < 8; ++a) { z[a] = lds_rd(&ex[a * kE2S + lp.rhoL]); z[8 + a] = lds_rd(&ex[a * kE2S + lp.rhoK]); }
 }
 __device__ __forceinline__ void ex2_put_cols(const v2f* z, v2f* ex, const LanePos& lp) {
+    GL_ABL_SKIP_EX;
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int a = 0; a < 8; ++a) { ex[a * kE2S + lp.rhoL] = z[a]; ex[a * kE2S + lp.rhoK] = z[8 + a]; }
     __builtin_amdgcn_wave_barrier();
 }
 __device__ __forceinline__ void ex2_get_rows(v2f* z, const v2f* ex, const LanePos& lp) {
+    GL_ABL_SKIP_EX;
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -380,13 +419,49 @@ __device__ __forceinline__ void middle_project(v2f* z, const float* m_lo, const 
     for (int c = 0; c < 8; ++c) { z[c] = P[c]; z[8 + c] = Q[7 - c]; }
 }
 
+// The same step for the n_fft-2048 kernels: magnitudes arrive as pairs mm[u] = (m[k_u], m[1024 - k_u]) (packed
+// layout below) and the zero-frame rule is the planted kZeroNudge (project2), so no per-bin nudge or clamp.
+template <class TAB>
+__device__ __forceinline__ void middle_project2(v2f* z, const v2f* mm, float m512, const TAB& tb) {
+    v2f P[9], Q[9];
+    const v2f z4 = z[4];
+    lane0_chain(z[4], z[8], z[12], z[5], z[9], z[13], z[6], z[10], z[14], z[7], z[11], z[15], z[0]);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { P[c] = z[c]; Q[c] = z[15 - c]; }
+    auto unit = [&](int u, v2f w) {
+        const v2f uu = pk_addc(P[u], Q[u]), vv = pk_subc(P[u], Q[u]);
+        v2f X = cmul_add(vv, w, uu), Y = cmul_sub(vv, w, uu);
+        project2(X, Y, mm[u]);
+        const v2f a2 = X + Y, b2 = X - Y;
+        P[u] = cmulc_add(b2, w, a2);
+        Q[u] = cmulc_subconj(b2, w, a2);
+    };
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+        v2f wa, wb;
+        tb.pair(kT2Twp + 2 * pp, wa, wb);
+        unit(2 * pp, wa);
+        unit(2 * pp + 1, wb);
+    }
+    // unit 8 = lane 0's bin 512, its own mirror (w = -1): the general formula collapses to 2 * project(z, m)
+    {
+        const float r = fmaf(z4.x, z4.x, fmaf(z4.y, z4.y, 0x1p-126f));
+        const float sc = (m512 + m512) * __builtin_amdgcn_rsqf(r);
+        P[8] = z4 * (v2f){sc, sc};
+    }
+    lane0_chain(Q[0], Q[4], P[7], Q[1], Q[5], P[6], Q[2], Q[6], P[5], Q[3], Q[7], P[4], P[8]);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { z[c] = P[c]; z[8 + c] = Q[7 - c]; }
+}
+
 // Magnitudes as the register-ring kernel's lanes consume them.  Lane l of a frame needs the 17
 // values m[k], m[1024-k] at its 8 mirror pairs k = l + 128u (lane 0: see middle_project) and
 // m[512]: 17 dword loads per frame, rows 4100 bytes long so every load straddles three 128-byte
 // lines.  The kernel is bound by the number of line requests a CU can keep in flight (TCP
 // pending-stall 46 % of cycles), so gl_run first repacks the spectrogram once into
 // [frame][quad q][lane][4] + [frame][1024 + lane]: four aligned dwordx4 loads and one dword per
-// frame, 34 line requests instead of about 51.  4352 bytes per frame (6 % more than 4100).
+// frame, 34 line requests instead of about 51.  4352 bytes per frame (6 % more than 4100).  Quad q of a lane
+// holds (m[k], m[1024-k]) of its mirror pairs u = 2q and 2q+1, so a pair's two magnitudes are one register pair.
 constexpr int kMagPack = 1088;
 // 1/M of the inverse transform and the factor 2 the split step leaves, folded into the magnitudes once
 // (a power of two: exact), so the forward and the inverse window are the same table entries

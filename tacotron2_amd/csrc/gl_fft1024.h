@@ -255,12 +255,53 @@ __device__ __forceinline__ void twiddle2(v2f* z, const TAB& tb) {   // z[d], z[8
 }
 // exchange 1: register k2 <-> lane bits g3.  "cols" side: 16 x b64 at pi(l); "rows" side: 2 x 4 x b128
 #if defined(GL_EXPERIMENT) && defined(GL_ABL)
+// Timing study (GL_ABL & 32; results are NOT a transform): the cost of exchange 1 -- register bits 0..2 against lane
+// bits 3..5 -- done in the register file instead of LDS, as the three butterfly stages of an 8 x 8 transpose:
+// v_permlane32_swap (lane bit 5), v_permlane16_swap (lane bit 4), each one instruction per VGPR pair, and lane
+// bit 3 by two DPP row_ror:8 selects per VGPR pair.  16 + 16 + 32 = 64 VALU operations per exchange.
+__device__ __forceinline__ void ex1_in_registers(v2f* z, int l) {
+    const bool hi = (l & 8) != 0;
+#pragma unroll
+    for (int k = 0; k < 16; k += 2) {          // register bit 0 <-> lane bit 5
+        auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(z[k].x), __float_as_uint(z[k + 1].x), false, false);
+        auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(z[k].y), __float_as_uint(z[k + 1].y), false, false);
+        z[k].x = __uint_as_float(a[0]); z[k + 1].x = __uint_as_float(a[1]);
+        z[k].y = __uint_as_float(b[0]); z[k + 1].y = __uint_as_float(b[1]);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {             // register bit 1 <-> lane bit 4
+        if (k & 2) continue;
+        auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(z[k].x), __float_as_uint(z[k + 2].x), false, false);
+        auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(z[k].y), __float_as_uint(z[k + 2].y), false, false);
+        z[k].x = __uint_as_float(a[0]); z[k + 2].x = __uint_as_float(a[1]);
+        z[k].y = __uint_as_float(b[0]); z[k + 2].y = __uint_as_float(b[1]);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {             // register bit 2 <-> lane bit 3: rotate by 8 inside each row of 16 lanes
+        if (k & 4) continue;
+        const float ax = z[k].x, ay = z[k].y, bx = z[k + 4].x, by = z[k + 4].y;
+        const float rbx = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(bx), 0x128, 0xf, 0xf, false));
+        const float rby = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(by), 0x128, 0xf, 0xf, false));
+        const float rax = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(ax), 0x128, 0xf, 0xf, false));
+        const float ray = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(ay), 0x128, 0xf, 0xf, false));
+        z[k].x = hi ? rbx : ax;      z[k].y = hi ? rby : ay;
+        z[k + 4].x = hi ? bx : rax;  z[k + 4].y = hi ? by : ray;
+    }
+}
+#endif
+
+#if defined(GL_EXPERIMENT) && defined(GL_ABL)
 #define GL_ABL_SKIP_EX if (GL_ABL & 1) return
+#define GL_ABL_EX1_REG_PUT if (GL_ABL & 32) return
+#define GL_ABL_EX1_REG_GET if (GL_ABL & 32) { ex1_in_registers(z, lp.a3 + 8 * lp.g3); return; }
 #else
 #define GL_ABL_SKIP_EX
+#define GL_ABL_EX1_REG_PUT
+#define GL_ABL_EX1_REG_GET
 #endif
 __device__ __forceinline__ void ex1_put_cols(const v2f* z, v2f* ex, const LanePos& lp) {
     GL_ABL_SKIP_EX;
+    GL_ABL_EX1_REG_PUT;
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int k2 = 0; k2 < 16; ++k2) ex[k2 * kE1S + lp.piL] = z[k2];
@@ -268,6 +309,7 @@ __device__ __forceinline__ void ex1_put_cols(const v2f* z, v2f* ex, const LanePo
 }
 __device__ __forceinline__ void ex1_get_rows(v2f* z, const v2f* ex, const LanePos& lp) {
     GL_ABL_SKIP_EX;
+    GL_ABL_EX1_REG_GET;
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -276,6 +318,7 @@ __device__ __forceinline__ void ex1_get_rows(v2f* z, const v2f* ex, const LanePo
 }
 __device__ __forceinline__ void ex1_put_rows(const v2f* z, v2f* ex, const LanePos& lp) {
     GL_ABL_SKIP_EX;
+    GL_ABL_EX1_REG_PUT;
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -286,6 +329,7 @@ __device__ __forceinline__ void ex1_put_rows(const v2f* z, v2f* ex, const LanePo
 }
 __device__ __forceinline__ void ex1_get_cols(v2f* z, const v2f* ex, const LanePos& lp) {
     GL_ABL_SKIP_EX;
+    GL_ABL_EX1_REG_GET;
 #pragma unroll
     for (int k2 = 0; k2 < 16; ++k2) z[k2] = lds_rd(&ex[k2 * kE1S + lp.piL]);
 }

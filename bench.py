@@ -6,9 +6,10 @@ iterations, n_fft 2048 / hop 256, 80-band synthetic mels (BASELINE.json).
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one pass of the hot path over one batch that is already resident in
-HBM: mel (B,80,T) -> linear magnitude on MFMA (gl_mel_to_mag), 60 fused
-Griffin-Lim iterations from a resident start signal (gl_run), peak normalisation
-(gl_peak_normalise).
+HBM: mel (B,80,T) -> linear magnitude on MFMA, 60 fused Griffin-Lim iterations
+from a resident start signal, peak normalisation (gl_peak_normalise).  The first
+two are ONE library call (gl_mel_run: the mel inversion stores the magnitudes in the
+loop kernel's own layout) unless --fused-mel 0 asks for gl_mel_to_mag + gl_run.
 
 Workloads.  Every utterance is a function of its GLOBAL index only
 (mel: numpy Generator seeded with (1234, id); start signal: elements
@@ -175,6 +176,9 @@ def main():
     ap.add_argument("--iters", type=int, default=60)
     ap.add_argument("--path", type=int, default=0, help="0 fused (default), 1 generic kernels")
     ap.add_argument("--run-frames", type=int, default=0, help="pin the frames-per-wave-run of the fused kernels (0 = automatic)")
+    ap.add_argument("--fused-mel", type=int, default=1,
+                    help="1: mel inversion and loop as ONE call (gl_mel_run: packed magnitudes, no (B,T,F) array, no "
+                         "repack pass) where the plan has it; 0: gl_mel_to_mag + gl_run")
     ap.add_argument("--graph", type=int, default=1, help="1: also time the step replayed from a captured hipGraph")
     ap.add_argument("--preroll-ms", type=float, default=40.0,
                     help="untimed steps before the W warmup steps until this much GPU time has passed: the card "
@@ -230,17 +234,28 @@ def main():
     x = torch.empty((B, L), dtype=torch.float32, device=dev)
 
     gl_ms = []
+    one_call = bool(args.fused_mel) and plan.mel_run_supported()
 
-    def step(timed):
-        plan.mel_to_mag(fb, mel, out=mag)
+    def mel_and_loop(timed=False):
+        """griffin_lim.py:18-24 for the batch.  The events bracket the K loop launches (torch's current stream is the
+        stream the library launches on); with the one-call form they also take in the mel inversion, without it
+        the repack pass -- either way 1/K of a ~0.1 ms kernel on top of each iteration."""
+        if not one_call:
+            plan.mel_to_mag(fb, mel, out=mag)
         if timed:
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
-            e0.record()                      # torch's current stream == the stream gl_run launches on
-        plan.run(mag, x0, K, out=x)
+            e0.record()
+        if one_call:
+            plan.mel_run(fb, mel, x0, K, out=x)
+        else:
+            plan.run(mag, x0, K, out=x)
         if timed:
             e1.record()
             gl_ms.append((e0, e1))
+
+    def step(timed):
+        mel_and_loop(timed)
         plan.peak_normalise(x, mode=0)
 
     def barrier():
@@ -276,8 +291,7 @@ def main():
     if args.graph:
         peaks = torch.empty((B,), dtype=torch.float32, device=dev)
         with plan.capture() as g:
-            plan.mel_to_mag(fb, mel, out=mag)
-            plan.run(mag, x0, K, out=x)
+            mel_and_loop()
             plan.peak_normalise(x, mode=0, peaks=peaks)
         x_stream = x.clone()
         for _ in range(max(1, args.warmup)):
@@ -324,9 +338,10 @@ def main():
                        "n_fft": N, "hop": H, "frames": T, "iters": K, "batch_per_gpu": B,
                        "global_batch": G, "audio_s_per_utt": L / SR,
                        "parallelism": f"utterance-sharded x{n_gpus}, no data-path collective",
-                       "kernel_path": "fused" if args.path == 0 else "generic"},
+                       "kernel_path": "fused" if args.path == 0 else "generic",
+                       "mel_inversion": "gl_mel_run (packed magnitudes, one call)" if one_call else "gl_mel_to_mag + gl_run"},
             "x_realtime_per_gpu": value / n_gpus,
-            "roofline": {"bound": "hbm", "kernel": "fused Griffin-Lim iteration (gl_run, one launch per iteration)",
+            "roofline": {"bound": "hbm", "kernel": "fused Griffin-Lim iteration (one launch per iteration)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": iter_ms,
@@ -340,8 +355,8 @@ def main():
             # un-normalised Griffin-Lim output of the batch once more (the timed step normalises in place), then the
             # first utterances back to the host for the CPU leg
             nu = min(4, B)
-            plan.mel_to_mag(fb, mel, out=mag)
-            plan.run(mag, x0, K, out=x)
+            mel_and_loop()                                 # the measured path's samples ...
+            plan.mel_to_mag(fb, mel, out=mag)              # ... and the magnitudes the oracle starts from
             torch.cuda.synchronize()
             mags = [mag[u].cpu().numpy() for u in range(nu)]
             x0s = [x0[u].cpu().numpy().astype(np.float64) for u in range(nu)]

@@ -126,6 +126,24 @@ int gl_wav_to_logmel(gl_plan* plan, const float* y, long long y_stride, long lon
 int gl_run(gl_plan* plan, const float* mag, const float* x0, float* x_out,
            int iters, int B, int T, void* stream);
 
+/* a-2 + a-3 in one call                                   griffin_lim.py:18-24
+ *   np.dot(filterbank.T, mel).T followed by reconstruct_signal_griffin_lim, without the [B][T][F] magnitude
+ *   array in between: the mel inversion stores the magnitudes straight in the per-lane order the loop's
+ *   kernels read (plan-owned), so the repacking pass gl_run starts with and one round trip of the magnitudes
+ *   through HBM are gone.  For callers that do not need the linear magnitude save_mel_to_wav returns
+ *   (griffin_lim.py:35) -- batched serving.  Results equal gl_mel_to_mag (+ gl_mask_frames) + gl_run bit for bit.
+ *   mel_layout 0 : mel [B][n_mels][T] linear amplitude (as gl_mel_to_mag; compression_factor ignored)
+ *   mel_layout 1 : mel [B][T][n_mels] natural-log amplitude (as gl_logmel_to_mag)
+ *   frames       : NULL, or [B] int32 on the device: frames t >= frames[b] get zero magnitude (gl_mask_frames)
+ *   x0, x_out, iters : as gl_run.
+ *   Exists where the loop reads packed magnitudes: n_fft 2048, hop 128/256/512/1024, default path, x0 and
+ *   x_out 8-byte aligned (gl_mel_run_supported tells for the plan); elsewhere GL_ERR_UNSUPPORTED and the
+ *   caller makes the two calls.                                                                              */
+int gl_mel_run_supported(const gl_plan* plan);
+int gl_mel_run(gl_plan* plan, const float* filterbank, const float* mel, int n_mels, int mel_layout,
+               float compression_factor, const int* frames, const float* x0, float* x_out, int iters,
+               int B, int T, void* stream);
+
 /* Ragged batches.  The reference reconstructs one utterance per call (audio_utilities.py:154), so
  * utterances of different lengths never meet; a batch here has one frame count T for all.  Zeroing
  * the magnitude rows t >= frames[b] makes the padding frames project to exactly zero (they add

@@ -52,7 +52,7 @@ int gl_plan_alloc(gl_plan* p, void** ptr, size_t bytes) {
 
 extern "C" {
 
-int gl_version(void) { return 200; }
+int gl_version(void) { return 201; }
 
 const char* gl_last_error(void) { return g_err; }
 
@@ -290,6 +290,40 @@ int gl_run(gl_plan* p, const float* mag, const float* x0, float* x_out, int iter
     }
     return use_fast(p, GL_FAST_OP_RUN) ? gl_fast_run(p, mag, x0, x_out, iters, B, T, st)
                        : gl_generic_run(p, mag, x0, x_out, iters, B, T, st);
+}
+
+int gl_mel_run_supported(const gl_plan* p) {
+    // aligned dummies: only the plan's geometry and path are asked about here
+    return p && use_fast(p, GL_FAST_OP_RUN) && gl_fast_takes_packed(p, nullptr, nullptr) ? 1 : 0;
+}
+
+int gl_mel_run(gl_plan* p, const float* filterbank, const float* mel, int n_mels, int mel_layout,
+               float compression_factor, const int* frames, const float* x0, float* x_out, int iters, int B, int T,
+               void* stream) {
+    int rc = check_call(p, B, T, "gl_mel_run");
+    if (rc) return rc;
+    if (!filterbank || !mel || !x0 || !x_out) return gl_set_error(GL_ERR_INVALID, "gl_mel_run: NULL buffer");
+    if (n_mels < 1 || n_mels > 4096) return gl_set_error(GL_ERR_INVALID, "gl_mel_run: n_mels=%d", n_mels);
+    if (mel_layout != 0 && mel_layout != 1) return gl_set_error(GL_ERR_INVALID, "gl_mel_run: mel_layout must be 0 or 1");
+    if (mel_layout == 1 && !(compression_factor > 0.0f))
+        return gl_set_error(GL_ERR_INVALID, "gl_mel_run: compression_factor must be > 0");
+    if (iters < 0) return gl_set_error(GL_ERR_INVALID, "gl_mel_run: iters=%d", iters);
+    if (!use_fast(p, GL_FAST_OP_RUN) || !gl_fast_takes_packed(p, x0, x_out))
+        return gl_set_error(GL_ERR_UNSUPPORTED,
+                            "gl_mel_run: this plan's loop reads plain magnitudes (needs n_fft 2048, hop 128, 256, 512 or "
+                            "1024, the default path and 8-byte aligned signals): call gl_mel_to_mag + gl_run");
+    DeviceGuard guard(p->device);
+    hipStream_t st = (hipStream_t)stream;
+    if (iters == 0) return gl_copy_rows(x_out, x0, (long long)B * gl_len(p->n_fft, p->hop, T), st);
+    rc = gl_mel_launch(filterbank, mel, p->d_magp, n_mels, p->n_fft / 2 + 1, B, T, mel_layout == 1,
+                       mel_layout == 1 ? compression_factor : 1.0f, (p->opt_flags & GL_OPT_CLAMP_MAG) != 0, p->n_cu, st,
+                       true, frames);
+    if (rc) return rc;
+    if (p->opt_flags & GL_OPT_WSUM_NORMALISE) {
+        rc = gl_wsum_enqueue(p, T, st);
+        if (rc) return rc;
+    }
+    return gl_fast_run_packed(p, x0, x_out, iters, B, T, st);
 }
 
 int gl_plan_prepare(gl_plan* p) {

@@ -799,8 +799,10 @@ int run_regring(gl_plan* p, const float* mag, const float* x0, float* x_out, int
                 hipStream_t st) {
     const int G = gl_fast_pick_run_length(p, B, T, kRRWaves);
     const int nruns = (T + G - 1) / G;
-    hipLaunchKernelGGL(k_mag_repack, dim3(T, B), dim3(64), 0, st, mag, p->d_magp, T);
-    GL_HIP_CHECK(hipGetLastError());
+    if (mag != nullptr) {            // null: the mel inversion stored the packed layout itself (gl_mel_run)
+        hipLaunchKernelGGL(k_mag_repack, dim3(T, B), dim3(64), 0, st, mag, p->d_magp, T);
+        GL_HIP_CHECK(hipGetLastError());
+    }
     // Too few frames to fill the GPU with runs: one wave per frame, state kept as frames (k_gl2048_frames).  Not
     // with a pinned run length (callers who pin it compare bits with the run kernel) nor with the optional
     // per-iteration signal transforms.  Measured at hop 256, T = 861 (us per iteration, per-frame form vs
@@ -930,6 +932,13 @@ int gl_fast_analysis_mag(gl_plan* p, const float* y, long long y_stride, long lo
     hipLaunchKernelGGL(k_analysis2048, dim3((unsigned)wgs), dim3(64 * kRRWaves), 0, st, a);
     GL_HIP_CHECK(hipGetLastError());
     return 0;
+}
+
+bool gl_fast_takes_packed(const gl_plan* p, const void* x0, const void* x_out) {
+    return p->path == 0 && p->n_fft == 2048 && p->d_magp != nullptr && regring_ok(p, x0, x_out);
+}
+int gl_fast_run_packed(gl_plan* p, const float* x0, float* x_out, int iters, int B, int T, hipStream_t st) {
+    return run_regring(p, nullptr, x0, x_out, iters, B, T, st);
 }
 
 // the Griffin-Lim loop at n_fft 2048: register rings where the hop allows, else the rings-in-LDS kernel

@@ -85,10 +85,15 @@ int gl_fast_analysis_mag(gl_plan* p, const float* y, long long y_stride, long lo
                          int B, int T, const float* win_p, hipStream_t st);
 int gl_fast_run(gl_plan* p, const float* mag, const float* x0, float* x_out, int iters, int B, int T,
                 hipStream_t st);
+// the loop on magnitudes ALREADY in p->d_magp (gl_mel_launch(packed) wrote them): gl_mel_run
+bool gl_fast_takes_packed(const gl_plan* p, const void* x0, const void* x_out);
+int gl_fast_run_packed(gl_plan* p, const float* x0, float* x_out, int iters, int B, int T, hipStream_t st);
 
 // ---- mel inversion (MFMA): gl_mel.hip ---------------------------------------------
+// packed: `mag` is [B][T][1088] in the register-ring kernels' own layout (n_fft 2048), rows t >= frames[b] zeroed
 int gl_mel_launch(const float* fb, const float* mel, float* mag, int n_mels, int F, int B, int T, bool logmel,
-                  float compression_factor, bool clamp, int n_cu, hipStream_t st);
+                  float compression_factor, bool clamp, int n_cu, hipStream_t st, bool packed = false,
+                  const int* frames = nullptr);
 
 int gl_mag_to_logmel_launch(const float* fb, const float* mag, float* logmel, int n_mels, int F, int B, int T,
                             float clip_min, float compression_factor, hipStream_t st);

@@ -23,6 +23,21 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 constexpr int kTileT = 32;      // rows (t) per wave
 constexpr int kNJ = 3;          // accumulators (32 bins each) per wave: F = 1025 is 33 blocks of 32 = 11 tiles of 3
 constexpr int kTileF = 32 * kNJ;
+// PACKED output (gl_mel_run): the register-ring Griffin-Lim kernels read a frame's magnitudes as [quad q][lane][4] =
+// (m[k], m[1024-k]) of the lane's mirror pairs u = 2q, 2q+1, then 64 copies of m[512], pre-scaled by 1/2048
+// (gl_fast2048.hip, k_mag_repack).  A tile is then 32 lanes x one quad = FOUR accumulators whose registers are the
+// four floats of one 16-byte store; 2 lane halves x 4 quads + 1 tile of bin 512 = 9 tiles of 128 columns.
+constexpr int kNJPacked = 4;
+constexpr int kPackedTiles = 9;
+constexpr int kPackRow = 1088;  // floats per packed frame (gl_fft1024.h: kMagPack)
+constexpr float kPackScale = 1.0f / 2048.0f;
+// bin of column c (0..3) of lane-column jj (0..31) of packed tile ft
+__device__ __forceinline__ int packed_bin(int ft, int jj, int c) {
+    if (ft == kPackedTiles - 1) return 512;
+    const int l = 32 * (ft & 1) + jj, u = 2 * (ft >> 1) + (c >> 1);
+    const int k = l ? l + 128 * u : (u < 4 ? 128 * u : 64 + 128 * (u - 4));   // lane 0 owns the multiples of 64
+    return (c & 1) ? 1024 - k : k;
+}
 constexpr int kWaves = 4;       // waves per workgroup, stacked along t
 constexpr int kKC = 80;         // mel bands per LDS stage of the filterbank tile (40 KB)
 // Resident workgroups per CU (3 waves per SIMD).  Measured on config 2 (64 x 861 frames, 80 bands): 109 us; 4 per
@@ -59,10 +74,14 @@ __device__ __forceinline__ void st_buf(float v, __amdgpu_buffer_rsrc_t rs, int v
 // XCD's L2 instead of leaving as partial writes from several.
 // FULLK: n_mels == kKC (80, the reference's n_mel_channels): one stage of B for the workgroup's life and a
 // branch-free K loop.  Otherwise B is restaged per group and chunk and every band is range-checked.
-template <bool LOGMEL, bool FULLK>
+// PACKED: F = 1025 only; `mag` is the packed [B][T][1088] array and `frames` (null, or [B]) zeroes the rows of
+// frames t >= frames[b] as gl_mask_frames does on the plain layout.
+template <bool LOGMEL, bool FULLK, bool PACKED>
 __global__ void __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(kWgPerCu, kWgPerCu)))
 k_mel_to_mag(const float* __restrict__ fb, const float* __restrict__ mel, float* __restrict__ mag, int K, int F,
-             int T, float inv_cf, float floor_val, int n_ftiles, int n_tblocks, int n_groups, int n_slots) {
+             int T, float inv_cf, float floor_val, int n_ftiles, int n_tblocks, int n_groups, int n_slots,
+             const int* __restrict__ frames) {
+    constexpr int NJ = PACKED ? kNJPacked : kNJ;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // tells the compiler it is uniform
     const int li = lane & 31;
@@ -82,12 +101,12 @@ k_mel_to_mag(const float* __restrict__ fb, const float* __restrict__ mel, float*
             const bool k_ok = kc + k < K;
             const float* row = fb + (long long)(k_ok ? kc + k : 0) * F;
             v4f v;
+            v[3] = 0.0f;
 #pragma unroll
-            for (int c = 0; c < kNJ; ++c) {
-                const int f = f0 + 32 * c + jj;
+            for (int c = 0; c < NJ; ++c) {
+                const int f = PACKED ? packed_bin(ft, jj, c) : f0 + 32 * c + jj;
                 v[c] = (k_ok && f < F) ? row[f] : 0.0f;
             }
-            v[3] = 0.0f;
             Bs[k][jj] = v;
         }
     };
@@ -124,23 +143,46 @@ k_mel_to_mag(const float* __restrict__ fb, const float* __restrict__ mel, float*
             }
         }
     };
-    auto mfma_chunk = [&](f32x16 (&acc)[kNJ], const float (&av)[kKC / 2], int kend) {
+    auto mfma_chunk = [&](f32x16 (&acc)[NJ], const float (&av)[kKC / 2], int kend) {
 #pragma unroll
         for (int s = 0; s < kKC / 2; ++s) {
             if (FULLK || 2 * s < kend) {                     // wave-uniform; rows past K are zero in Bs and av
                 const v4f bv = Bs[2 * s + lk][li];
 #pragma unroll
-                for (int j = 0; j < kNJ; ++j)
+                for (int j = 0; j < NJ; ++j)
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[j], acc[j], 0, 0, 0);
             }
             // Without a fence the scheduler hoists all 40 ds_read_b128 (160 VGPRs) above the first MFMA.
             if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
     };
-    auto store = [&](int g, const f32x16 (&acc)[kNJ]) {
+    auto store = [&](int g, const f32x16 (&acc)[NJ]) {
         const int b = g / n_tblocks;
         const int t0 = ((g - b * n_tblocks) * kWaves + wave) * kTileT;
         if (t0 >= T) return;
+        if constexpr (PACKED) {
+            // registers r of the four accumulators = the quad (m[k], m[1024-k], m[k'], m[1024-k']) of lane
+            // 32 (ft & 1) + li for frame t0 + row(r): one 16-byte store, 512 contiguous bytes per half-wave
+            const bool m512 = ft == kPackedTiles - 1;                 // 64 copies of bin 512: lanes li < 16 store
+            float* base = mag + ((long long)b * T + t0) * kPackRow + (m512 ? 1024 : (ft >> 1) * 256 + (ft & 1) * 128);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, kRsrcBytes, kRsrcFlags);
+            const int lane_off = (4 * lk * kPackRow + 4 * li) * 4;
+            const int t_end = frames ? min(frames[b], T) : T;         // rows from t_end on are written as zeros
+            if (m512 && li >= 16) return;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ro = (r & 3) + 8 * (r >> 2);
+                const int t = t0 + ro + 4 * lk;
+                if (t >= T) continue;
+                const float live = t < t_end ? kPackScale : 0.0f;
+                typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                v4f v;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) v[j] = fmaxf(acc[j][r], floor_val) * live;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), rs, lane_off, ro * kPackRow * 4, 0);
+            }
+            return;
+        }
         float* base = mag + ((long long)b * T + t0) * F + f0;   // wave-uniform
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, kRsrcBytes, kRsrcFlags);
         const int lane_off = (4 * lk * F + li) * 4;
@@ -164,9 +206,9 @@ k_mel_to_mag(const float* __restrict__ fb, const float* __restrict__ mel, float*
             }
         }
     };
-    auto zero = [&](f32x16 (&acc)[kNJ]) {
+    auto zero = [&](f32x16 (&acc)[NJ]) {
 #pragma unroll
-        for (int j = 0; j < kNJ; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
     };
@@ -177,14 +219,14 @@ k_mel_to_mag(const float* __restrict__ fb, const float* __restrict__ mel, float*
         for (int g = g_first; g < n_groups; g += g_step) {
             float av[kKC / 2];
             load_a(g, 0, av);
-            f32x16 acc[kNJ];
+            f32x16 acc[NJ];
             zero(acc);
             mfma_chunk(acc, av, K);
             store(g, acc);
         }
     } else {
         for (int g = g_first; g < n_groups; g += g_step) {   // workgroup-uniform trip count
-            f32x16 acc[kNJ];
+            f32x16 acc[NJ];
             zero(acc);
             for (int kc = 0; kc < K; kc += kKC) {
                 float av[kKC / 2];
@@ -326,9 +368,10 @@ int gl_mag_to_logmel_launch(const float* fb, const float* mag, float* logmel, in
 }
 
 int gl_mel_launch(const float* fb, const float* mel, float* mag, int n_mels, int F, int B, int T, bool logmel,
-                  float compression_factor, bool clamp, int n_cu, hipStream_t st) {
+                  float compression_factor, bool clamp, int n_cu, hipStream_t st, bool packed, const int* frames) {
     const float floor_val = clamp ? 0.0f : -INFINITY;     // GL_OPT_CLAMP_MAG (pseudo-inverse bases go negative)
-    const int n_ftiles = (F + kTileF - 1) / kTileF;
+    if (packed && F != 1025) return gl_set_error(GL_ERR_INVALID, "packed magnitudes exist for n_fft 2048 only");
+    const int n_ftiles = packed ? kPackedTiles : (F + kTileF - 1) / kTileF;
     const int n_tblocks = (T + kTileT * kWaves - 1) / (kTileT * kWaves);
     const int n_groups = n_tblocks * B;
     // One round of resident workgroups: per XCD (n_cu / 8 CUs) kWgPerCu per CU, shared by the F-tiles.
@@ -337,10 +380,13 @@ int gl_mel_launch(const float* fb, const float* mel, float* mag, int n_mels, int
     if (n_slots > (n_groups + 7) / 8) n_slots = (n_groups + 7) / 8;
     dim3 grid((unsigned)(8 * n_ftiles * n_slots));
     const float inv_cf = logmel ? 1.0f / compression_factor : 1.0f;
-    auto kern = logmel ? (n_mels == kKC ? k_mel_to_mag<true, true> : k_mel_to_mag<true, false>)
-                       : (n_mels == kKC ? k_mel_to_mag<false, true> : k_mel_to_mag<false, false>);
+    const bool fullk = n_mels == kKC;
+    auto kern = packed ? (logmel ? (fullk ? k_mel_to_mag<true, true, true> : k_mel_to_mag<true, false, true>)
+                                 : (fullk ? k_mel_to_mag<false, true, true> : k_mel_to_mag<false, false, true>))
+                       : (logmel ? (fullk ? k_mel_to_mag<true, true, false> : k_mel_to_mag<true, false, false>)
+                                 : (fullk ? k_mel_to_mag<false, true, false> : k_mel_to_mag<false, false, false>));
     hipLaunchKernelGGL(kern, grid, dim3(64 * kWaves), 0, st, fb, mel, mag, n_mels, F, T, inv_cf, floor_val, n_ftiles,
-                       n_tblocks, n_groups, n_slots);
+                       n_tblocks, n_groups, n_slots, frames);
     GL_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -46,7 +46,7 @@ def _device_filterbank(fb, dev):
 
 def mel_to_audio(mel_spectrogram, *, basis=None, n_fft=None, hop=None, iterations=None, x_init=None, seed=None,
                  rng="numpy", normalize="reference", device=None, window_sum_normalize=False, momentum=0.0,
-                 lengths=None, run_frames=None):
+                 lengths=None, run_frames=None, return_mag=True):
     """Batched core of save_mel_to_wav, everything on the GPU.
 
     mel_spectrogram: (n_mels, T) or (B, n_mels, T), numpy or torch (linear-amplitude
@@ -57,7 +57,10 @@ def mel_to_audio(mel_spectrogram, *, basis=None, n_fft=None, hop=None, iteration
     audio_utilities.reconstruct_signal_griffin_lim.  normalize: 'reference' (divide by the
     peak only when it exceeds 1, griffin_lim.py:27-29), 'peak' (always) or None.  run_frames: pin the
     frames-per-wave-run for this call (shards of one batch then reproduce the whole batch bit for bit).
-    Returns (waveforms (B, L) fp32 torch on device, magnitude (B, T, F) fp32 torch)."""
+    return_mag=False: the caller does not want the linear magnitude save_mel_to_wav returns (griffin_lim.py:35);
+    where the plan has it the inversion and the loop are then ONE library call (gl_mel_run) that never
+    materialises the (B, T, F) array -- same samples, bit for bit.
+    Returns (waveforms (B, L) fp32 torch on device, magnitude (B, T, F) fp32 torch or None)."""
     n_fft = int(params.n_fft if n_fft is None else n_fft)
     hop = int(params.frame_hop if hop is None else hop)
     iterations = int(params.griffin_lim_iters if iterations is None else iterations)
@@ -89,15 +92,20 @@ def mel_to_audio(mel_spectrogram, *, basis=None, n_fft=None, hop=None, iteration
         raise ValueError(f"basis/filterbank shape {tuple(fb_dev.shape)} does not match "
                          f"({n_mels}, {n_fft // 2 + 1})")
     plan = get_plan(n_fft, hop, T, B, dev)
-    mag = plan.mel_to_mag(fb_dev, mel, clamp=clamp)          # griffin_lim.py:18-19
-    if lengths is not None:
-        if window_sum_normalize:
-            raise ValueError("window_sum_normalize needs each utterance's own window sum: not with lengths=")
-        plan.mask_frames(mag, lengths)
+    if lengths is not None and window_sum_normalize:
+        raise ValueError("window_sum_normalize needs each utterance's own window sum: not with lengths=")
     L = plan.signal_length(T)
     x0 = audio_utilities._start_signal(B, L, x_init, seed, rng, plan, dev)
-    x = plan.run(mag, x0, iterations, out=x0, normalize=window_sum_normalize, momentum=momentum,
-                 run_frames=run_frames)                                                              # :23-24
+    if not return_mag and plan.mel_run_supported():
+        mag = None
+        x = plan.mel_run(fb_dev, mel.contiguous(), x0, iterations, out=x0, clamp=clamp, lengths=lengths,
+                         normalize=window_sum_normalize, momentum=momentum, run_frames=run_frames)   # :18-24
+    else:
+        mag = plan.mel_to_mag(fb_dev, mel, clamp=clamp)          # griffin_lim.py:18-19
+        if lengths is not None:
+            plan.mask_frames(mag, lengths)
+        x = plan.run(mag, x0, iterations, out=x0, normalize=window_sum_normalize, momentum=momentum,
+                     run_frames=run_frames)                                                          # :23-24
     if lengths is not None:
         audio_utilities._zero_past(x, lengths, hop, n_fft)
     if normalize == "reference":
@@ -110,14 +118,16 @@ def mel_to_audio(mel_spectrogram, *, basis=None, n_fft=None, hop=None, iteration
 
 
 def logmel_to_audio(y_pred_post, *, compression_factor=1.0, basis=None, n_fft=None, hop=None, iterations=None,
-                    x_init=None, seed=None, rng="numpy", normalize="reference", device=None, lengths=None):
+                    x_init=None, seed=None, rng="numpy", normalize="reference", device=None, lengths=None,
+                    return_mag=True):
     """infer.py:24-29 without the host round trip: the decoder output goes in as it is.
 
     y_pred_post: (B, T, n_mels) or (T, n_mels) natural-log mel (Tacotron2.inference's second
     result), numpy or torch.  dynamic_range_decompression (data.py:84-85), the transpose of
     infer.py:28 and the filterbank contraction run in ONE kernel (gl_logmel_to_mag); then Griffin-Lim
     and the normalisation of save_mel_to_wav.  Unlike the reference (batch forced to 1,
-    model.py:530) any batch size is accepted.  Returns (waveforms (B, L), magnitude (B, T, F))."""
+    model.py:530) any batch size is accepted.  return_mag=False: see mel_to_audio.
+    Returns (waveforms (B, L), magnitude (B, T, F) or None)."""
     n_fft = int(params.n_fft if n_fft is None else n_fft)
     hop = int(params.frame_hop if hop is None else hop)
     iterations = int(params.griffin_lim_iters if iterations is None else iterations)
@@ -142,12 +152,17 @@ def logmel_to_audio(y_pred_post, *, compression_factor=1.0, basis=None, n_fft=No
         raise ValueError(f"basis/filterbank shape {tuple(fb_dev.shape)} does not match "
                          f"({n_mels}, {n_fft // 2 + 1})")
     plan = get_plan(n_fft, hop, T, B, dev)
-    mag = plan.logmel_to_mag(fb_dev, lm, compression_factor)
-    if lengths is not None:                 # ragged batch: decoder frames past an utterance's end are ignored
-        plan.mask_frames(mag, lengths)
     L = plan.signal_length(T)
     x0 = audio_utilities._start_signal(B, L, x_init, seed, rng, plan, dev)
-    x = plan.run(mag, x0, iterations, out=x0)
+    if not return_mag and plan.mel_run_supported():
+        mag = None
+        x = plan.mel_run(fb_dev, lm, x0, iterations, out=x0, logmel=True, compression_factor=compression_factor,
+                         lengths=lengths)
+    else:
+        mag = plan.logmel_to_mag(fb_dev, lm, compression_factor)
+        if lengths is not None:             # ragged batch: decoder frames past an utterance's end are ignored
+            plan.mask_frames(mag, lengths)
+        x = plan.run(mag, x0, iterations, out=x0)
     if lengths is not None:
         audio_utilities._zero_past(x, lengths, hop, n_fft)
     if normalize == "reference":
@@ -163,7 +178,7 @@ def infer_to_wav(y_pred_post, filenames=None, **kw):
     """Batched counterpart of infer.py:27-29: log-mel batch -> one WAV per utterance under
     params.audio_out_path ("Inference.wav" for a single utterance, like the reference).  The PCM
     encode runs on the device too (gl_pcm16_encode).  Returns the list of paths."""
-    x, _ = logmel_to_audio(y_pred_post, **kw)
+    x, _ = logmel_to_audio(y_pred_post, return_mag=False, **kw)
     B = x.shape[0]
     if filenames is None:
         filenames = ["Inference"] if B == 1 else ["Inference_%d" % i for i in range(B)]

@@ -219,6 +219,39 @@ class Plan:
                                         int(iterations), B, T, _stream_ptr(self.device)), "gl_run")
         return out
 
+    def mel_run_supported(self, path=None):
+        """True where mel_run exists: the loop of this plan reads packed magnitudes (n_fft 2048, hop
+        128/256/512/1024) and the call would take the default path."""
+        if (self._path if path is None else int(path)) != 0:
+            return False
+        return bool(self._lib.gl_mel_run_supported(self._h))
+
+    def mel_run(self, filterbank, mel, x0, iterations, out=None, logmel=False, compression_factor=1.0, clamp=False,
+                lengths=None, normalize=False, momentum=0.0, run_frames=None):
+        """mel_to_mag / logmel_to_mag (+ mask_frames) + run in one call that never materialises the (B, T, F)
+        magnitudes (gl_mel_run): mel (B, n_mels, T) linear, or with logmel=True (B, T, n_mels) natural log.
+        lengths: frames per utterance (ragged batch) or None.  Same samples as the separate calls, bit for bit."""
+        self.set_options(window_sum_normalize=normalize, clamp_mag=clamp, momentum=momentum)
+        if logmel:
+            B, T, n_mels = mel.shape
+        else:
+            B, n_mels, T = mel.shape
+        L = self.signal_length(T)
+        if out is None:
+            out = torch.empty((B, L), dtype=torch.float32, device=self.device)
+        lens = None
+        if lengths is not None:
+            lens = torch.as_tensor(lengths, dtype=torch.int32).to(self.device).contiguous()
+            if tuple(lens.shape) != (B,):
+                raise ValueError(f"lengths must have shape ({B},)")
+        with self._scoped(None, run_frames), torch.cuda.device(self.device):
+            _lib.check(self._lib.gl_mel_run(self._h, self._f32(filterbank, (n_mels, self.n_bins)), self._f32(mel),
+                                            n_mels, 1 if logmel else 0, float(compression_factor),
+                                            ctypes.c_void_p(lens.data_ptr()) if lens is not None else None,
+                                            self._f32(x0, (B, L)), self._f32(out, (B, L)), int(iterations), B, T,
+                                            _stream_ptr(self.device)), "gl_mel_run")
+        return out
+
     def randn(self, shape, seed, offset=0):
         """Standard normals from the device Philox stream of `seed`, starting at element `offset`."""
         out = torch.empty(shape, dtype=torch.float32, device=self.device)

@@ -810,3 +810,93 @@ def test_every_form_agrees_with_generic_on_random_geometries():
             assert np.isfinite(got).all()
             assert peak_err(got, ref) <= 2e-4, (N, H, T, B, K, pin, peak_err(got, ref))
             assert np.all(got[:, -H:] == 0.0), (N, H, T, B, K, pin)
+
+
+# ---- a-2 + a-3 in one call (gl_mel_run): no (B, T, F) magnitudes, no repack -------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,T,B,K,run_frames", [(256, 300, 5, 6, None),     # run kernel
+                                                 (256, 40, 2, 6, None),      # small problem: per-frame form
+                                                 (512, 97, 3, 4, 9),
+                                                 (128, 130, 2, 3, None),
+                                                 (1024, 33, 2, 3, None)])
+@pytest.mark.parametrize("logmel", [False, True])
+def test_mel_run_equals_the_separate_calls_bitwise(H, T, B, K, run_frames, logmel):
+    N, n_mels = 2048, 80
+    rng = np.random.default_rng(H + T)
+    fb = torch.from_numpy(filters.mel(sr=22050, n_fft=N, n_mels=n_mels, fmin=0.0, fmax=8000.0)).cuda()
+    lin = np.abs(rng.standard_normal((B, n_mels, T))).astype(np.float32) + 0.01
+    plan = Plan(N, H, T, B)
+    assert plan.mel_run_supported()
+    x0 = plan.randn((B, plan.signal_length(T)), seed=5)
+    lengths = [T] + [max(1, T - 7 * (i + 1)) for i in range(B - 1)]
+    if logmel:
+        mel = torch.from_numpy(np.log(lin).transpose(0, 2, 1).copy()).cuda()
+        mag = plan.logmel_to_mag(fb, mel, 2.0)
+    else:
+        mel = torch.from_numpy(lin).cuda()
+        mag = plan.mel_to_mag(fb, mel)
+    for lens in (None, lengths):
+        m = mag.clone()
+        if lens is not None:
+            plan.mask_frames(m, lens)
+        want = plan.run(m, x0, K, run_frames=run_frames)
+        got = plan.mel_run(fb, mel, x0, K, logmel=logmel, compression_factor=2.0, lengths=lens, run_frames=run_frames)
+        assert torch.equal(got, want), (H, T, logmel, lens is not None, float((got - want).abs().max()))
+    # the variants go through the same post pass
+    want = plan.run(mag, x0, K, normalize=True, momentum=0.5, run_frames=run_frames)
+    got = plan.mel_run(fb, mel, x0, K, logmel=logmel, compression_factor=2.0, normalize=True, momentum=0.5,
+                       run_frames=run_frames)
+    assert torch.equal(got, want)
+    assert torch.equal(plan.mel_run(fb, mel, x0, 0, logmel=logmel), x0)
+
+
+@pytest.mark.gpu
+def test_mel_run_pinv_basis_clamps_like_mel_to_mag():
+    N, H, T, B, n_mels = 2048, 256, 120, 2, 80
+    rng = np.random.default_rng(3)
+    fbn = filters.mel(sr=22050, n_fft=N, n_mels=n_mels, fmin=0.0, fmax=8000.0)
+    basis = torch.from_numpy(np.ascontiguousarray(filters.pinv_basis(fbn).T, dtype=np.float32)).cuda()   # (n_mels, F)
+    mel = torch.from_numpy(np.abs(rng.standard_normal((B, n_mels, T))).astype(np.float32)).cuda()
+    plan = Plan(N, H, T, B)
+    x0 = plan.randn((B, plan.signal_length(T)), seed=6)
+    mag = plan.mel_to_mag(basis, mel, clamp=True)
+    assert float(mag.min()) == 0.0                                  # the clamp is at work on this basis
+    want = plan.run(mag, x0, 4)
+    got = plan.mel_run(basis, mel, x0, 4, clamp=True)
+    assert torch.equal(got, want)
+
+
+@pytest.mark.gpu
+def test_mel_run_is_refused_where_the_loop_reads_plain_magnitudes():
+    fb80 = torch.zeros((80, 513), device="cuda")
+    plan = Plan(1024, 275, 50, 1)
+    assert not plan.mel_run_supported()
+    mel = torch.ones((1, 80, 50), device="cuda")
+    x0 = torch.zeros((1, plan.signal_length(50)), device="cuda")
+    with pytest.raises(RuntimeError, match="gl_mel_run"):
+        plan.mel_run(fb80, mel, x0, 2)
+    plan = Plan(2048, 300, 50, 1)                                   # n_fft 2048 at a hop the register rings do not take
+    assert not plan.mel_run_supported()
+    plan = Plan(2048, 256, 50, 1)
+    assert plan.mel_run_supported() and not plan.mel_run_supported(path=1)
+
+
+@pytest.mark.gpu
+def test_high_level_calls_without_the_magnitude_give_the_same_samples():
+    rng = np.random.default_rng(11)
+    mel = np.abs(rng.standard_normal((3, 80, 150))).astype(np.float32) + 0.01
+    lengths = [150, 120, 77]
+    kw = dict(n_fft=2048, hop=256, iterations=5, seed=3)
+    x_ref, mag = griffin_lim.mel_to_audio(mel, lengths=lengths, **kw)
+    x_one, none = griffin_lim.mel_to_audio(mel, lengths=lengths, return_mag=False, **kw)
+    assert none is None and mag.shape == (3, 150, 1025)
+    assert torch.equal(x_one, x_ref)
+    lm = np.log(mel).transpose(0, 2, 1).copy()
+    y_ref, _ = griffin_lim.logmel_to_audio(lm, lengths=lengths, **kw)
+    y_one, none = griffin_lim.logmel_to_audio(lm, lengths=lengths, return_mag=False, **kw)
+    assert none is None and torch.equal(y_one, y_ref)
+    # a geometry without the one-call form falls back to the two calls and still returns no magnitude
+    kw5 = dict(n_fft=1024, hop=275, iterations=3, seed=3)
+    z_ref, _ = griffin_lim.mel_to_audio(mel, **kw5)
+    z_one, none = griffin_lim.mel_to_audio(mel, return_mag=False, **kw5)
+    assert torch.equal(z_one, z_ref)

@@ -900,3 +900,25 @@ def test_high_level_calls_without_the_magnitude_give_the_same_samples():
     z_ref, _ = griffin_lim.mel_to_audio(mel, **kw5)
     z_one, none = griffin_lim.mel_to_audio(mel, return_mag=False, **kw5)
     assert torch.equal(z_one, z_ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H", [275, 114, 256, 512, 700, 1024])
+def test_n1024_run_kernel_seams_lone_frames_and_run_lengths(H):
+    """k_gl1024_pair2 (specialised at the reference's hop 275, general otherwise): every way a run can end -- even
+    and odd frame counts (a lone last frame), runs of the minimum length, of one pair, a last run of a single
+    frame -- and the seams between runs, against the any-N kernels after one and after three iterations."""
+    N, B = 1024, 2
+    rng = np.random.default_rng(H)
+    g_min = max(1, -(-(N - H) // H))
+    for T in (1, 2, 3, 4, 5, 12, 13, 40, 41):
+        mag = torch.from_numpy(np.abs(rng.standard_normal((B, T, N // 2 + 1))).astype(np.float32)).cuda()
+        x0 = torch.from_numpy(rng.standard_normal((B, T * H + N)).astype(np.float32)).cuda()
+        plan = Plan(N, H, T, B)
+        for K, tol in ((1, 3e-6), (3, 3e-5)):
+            ref = plan.run(mag, x0, K, path=1).cpu().numpy()
+            for G in sorted({g_min, g_min + 1, 4, 9, 16}):
+                got = plan.run(mag, x0, K, run_frames=G).cpu().numpy()
+                assert peak_err(got, ref) <= tol, (H, T, K, G, peak_err(got, ref))
+                assert np.all(got[:, -H:] == 0.0)
+        plan.close()

@@ -922,3 +922,26 @@ def test_n1024_run_kernel_seams_lone_frames_and_run_lengths(H):
                 assert peak_err(got, ref) <= tol, (H, T, K, G, peak_err(got, ref))
                 assert np.all(got[:, -H:] == 0.0)
         plan.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_mels", [1, 40, 81, 100, 200])
+def test_mel_run_other_band_counts(n_mels):
+    """The packed-layout instances of the mel inversion that restage the basis per 80-band chunk (n_mels != 80)."""
+    N, H, T, B, K = 2048, 256, 70, 2, 3
+    rng = np.random.default_rng(n_mels)
+    fb = torch.from_numpy(np.abs(rng.standard_normal((n_mels, N // 2 + 1))).astype(np.float32)).cuda()
+    lin = np.abs(rng.standard_normal((B, n_mels, T))).astype(np.float32) + 0.01
+    plan = Plan(N, H, T, B)
+    x0 = plan.randn((B, plan.signal_length(T)), seed=9)
+    for logmel in (False, True):
+        mel = torch.from_numpy(np.log(lin).transpose(0, 2, 1).copy() if logmel else lin).cuda()
+        mag = plan.logmel_to_mag(fb, mel, 1.5) if logmel else plan.mel_to_mag(fb, mel)
+        ref = np.einsum("bmt,mf->btf", lin.astype(np.float64) / (1.5 if logmel else 1.0), fb.cpu().numpy().astype(np.float64))
+        assert peak_err(mag.cpu().numpy(), ref) <= 1e-5
+        want = plan.run(mag, x0, K)
+        got = plan.mel_run(fb, mel, x0, K, logmel=logmel, compression_factor=1.5, lengths=[T, T - 9])
+        m = mag.clone()
+        plan.mask_frames(m, [T, T - 9])
+        assert torch.equal(got, plan.run(m, x0, K))
+        assert torch.equal(plan.mel_run(fb, mel, x0, K, logmel=logmel, compression_factor=1.5), want)

@@ -112,6 +112,20 @@ int gl_wav_to_logmel(gl_plan* plan, const float* y, long long y_stride, long lon
                      float* mag, float* logmel, int n_mels, int pad_mode, float clip_min, float compression_factor,
                      int B, void* stream);
 
+/* N3  the sample-rate conversion inside librosa.load(path), data.py:101 (default sr = 22 050 Hz, res_type
+ *   'kaiser_best' in the librosa 0.6 / 0.7 of the reference's Python 3.7 environment = resampy 0.2's
+ *   band-limited sinc interpolation: 64 zero crossings, 512 table points per crossing read with linear
+ *   interpolation, Kaiser window beta 14.769656459379492, roll-off 0.9475937167399596, filter scaled by the
+ *   ratio when downsampling).  y has gl_resample_length = ceil(n_in * sr_out / sr_in) samples like
+ *   librosa.resample (the last one is zero where int(n_in * ratio) is smaller: librosa.util.fix_length).
+ *   x : [B][x_stride] fp32 (n_in valid samples each);  y : [B][y_stride] fp32.  Neither librosa nor resampy
+ *   is pinned by the reference or available here: parity unpinned, checked against a numpy statement of the
+ *   algorithm and, for band-limited signals, against scipy's polyphase resampler.  The reference's own data
+ *   (LJSpeech) is already at 22 050 Hz, so its pipeline never resamples.                                  */
+long long gl_resample_length(long long n_in, int sr_in, int sr_out);
+int gl_resample(gl_plan* plan, const float* x, long long x_stride, long long n_in, float* y, long long y_stride,
+                int sr_in, int sr_out, int B, void* stream);
+
 /* a-3 + a-6  reconstruct_signal_griffin_lim(mag, fft_size, hopsamp, iterations)
  *                                                     audio_utilities.py:154-188
  *   mag   : [B][T][F] fp32   (rows = time slices)

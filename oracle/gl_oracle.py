@@ -301,3 +301,63 @@ def pcm16_from_float(x):
     x /= peak
     x *= 32767.0
     return np.rint(x).astype('<i2')
+
+
+# ---- N3: the sample-rate conversion inside librosa.load (data.py:101) -----------------------------------
+# TEST INFRASTRUCTURE (like the rest of this file).  Neither librosa nor resampy is in /root/reference or in this
+# container: PARITY UNPINNED.  What is restated is the published algorithm of resampy 0.2.x, the resampler behind
+# librosa.load's default res_type 'kaiser_best' in the librosa 0.6 / 0.7 of the reference's Python 3.7 environment
+# (venv/pyvenv.cfg): resampy.filters.sinc_window for the filter, resampy.interpn.resample_f for the interpolation,
+# librosa.core.resample for the output length (ceil) and the zero padding (util.fix_length).
+RS_ZEROS, RS_PRECISION = 64, 9
+RS_BETA, RS_ROLLOFF = 14.769656459379492, 0.9475937167399596
+
+
+def kaiser_best_filter():
+    """(interp_win, num_table): right wing of the windowed sinc, 2**precision points per zero crossing."""
+    num_bits = 2 ** RS_PRECISION
+    n = num_bits * RS_ZEROS
+    sinc_win = RS_ROLLOFF * np.sinc(RS_ROLLOFF * np.linspace(0, RS_ZEROS, num=n + 1, endpoint=True))
+    taper = np.kaiser(2 * n + 1, RS_BETA)[n:]
+    return taper * sinc_win, num_bits
+
+
+def resample_kaiser_best(x, sr_in, sr_out):
+    """librosa.resample(x, sr_in, sr_out) for a 1-D float32 signal, resampy's loop order and float32 running sum."""
+    x = np.asarray(x, dtype=np.float32)
+    ratio = float(sr_out) / float(sr_in)
+    n_out = int(np.ceil(x.shape[0] * ratio))
+    n_calc = min(int(x.shape[0] * ratio), n_out)
+    interp_win, num_table = kaiser_best_filter()
+    if ratio < 1:
+        interp_win = interp_win * ratio
+    interp_delta = np.zeros_like(interp_win)
+    interp_delta[:-1] = np.diff(interp_win)
+    scale = min(1.0, ratio)
+    time_increment = 1.0 / ratio
+    index_step = int(scale * num_table)
+    nwin = interp_win.shape[0]
+    n_orig = x.shape[0]
+    y = np.zeros(n_out, dtype=np.float32)
+    for t in range(n_calc):
+        time_register = t * time_increment
+        n = int(time_register)
+        frac = scale * (time_register - n)
+        index_frac = frac * num_table
+        offset = int(index_frac)
+        eta = index_frac - offset
+        i_max = min(n + 1, (nwin - offset) // index_step)
+        acc = np.float32(0.0)
+        for i in range(i_max):
+            weight = interp_win[offset + i * index_step] + eta * interp_delta[offset + i * index_step]
+            acc = np.float32(np.float64(acc) + weight * np.float64(x[n - i]))
+        frac = scale - frac
+        index_frac = frac * num_table
+        offset = int(index_frac)
+        eta = index_frac - offset
+        k_max = min(n_orig - n - 1, (nwin - offset) // index_step)
+        for k in range(k_max):
+            weight = interp_win[offset + k * index_step] + eta * interp_delta[offset + k * index_step]
+            acc = np.float32(np.float64(acc) + weight * np.float64(x[n + k + 1]))
+        y[t] = acc
+    return y

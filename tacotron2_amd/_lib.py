@@ -46,6 +46,9 @@ SIGNATURES = {
     "gl_mel_run": (ctypes.c_int, [_plan_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                   ctypes.c_void_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                   ctypes.c_void_p]),
+    "gl_resample_length": (ctypes.c_longlong, [ctypes.c_longlong, ctypes.c_int, ctypes.c_int]),
+    "gl_resample": (ctypes.c_int, [_plan_p, _c_float_p, ctypes.c_longlong, ctypes.c_longlong, _c_float_p,
+                                   ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "gl_plan_prepare": (ctypes.c_int, [_plan_p]),
     "gl_graph_begin": (ctypes.c_int, [ctypes.c_void_p]),
     "gl_graph_end": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]),

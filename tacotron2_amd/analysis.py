@@ -57,8 +57,42 @@ def audio_to_mel(y, *, n_fft=None, hop=None, filterbank=None, pad_mode="reflect"
     return (logmel, mag) if return_magnitude else logmel
 
 
+def resample(y, orig_sr, target_sr, device=None):
+    """librosa.resample(y, orig_sr, target_sr) with its default res_type of the reference's era ('kaiser_best' =
+    resampy's band-limited sinc interpolation) on the GPU (gl_resample).  y: (n,) or (B, n), numpy or torch;
+    returns ceil(n * target_sr / orig_sr) samples per row, float32, of the same kind as y.  Parity unpinned
+    (neither librosa nor resampy is available): see gl_hip.h."""
+    dev = audio_utilities._pick_device(device, y)
+    yt, was_np = audio_utilities._to_device(y, dev, torch.float32)
+    single = yt.dim() == 1
+    if single:
+        yt = yt[None]
+    if yt.dim() != 2:
+        raise ValueError("y must be (n,) or (B, n)")
+    if int(orig_sr) == int(target_sr):
+        out = yt.clone()
+    else:
+        params = griffin_lim.params
+        plan = get_plan(params.n_fft, params.n_fft // 4, 1, 1, dev)         # any plan carries the filter table
+        out = plan.resample(yt, orig_sr, target_sr)
+    if single:
+        out = out[0]
+    return out.cpu().numpy() if was_np else out
+
+
+def load(path, sr=22050, device=None):
+    """librosa.load(path, sr=22050) for wav files (data.py:101): mono float32 at `sr`, resampled when the file's
+    rate differs; sr=None keeps the file's rate.  Returns (y, sr) like librosa."""
+    fs, y = audio_utilities._read_wav(str(path))
+    y = np.asarray(y, dtype=np.float32)
+    if sr is None or int(sr) == int(fs):
+        return y, int(fs)
+    return resample(y, fs, sr, device=device), int(sr)
+
+
 def audiopath_to_mel(path, **kw):
-    """data.py:100-116 for a 16-bit / 32-bit PCM or float wav already at params.sampling_rate
-    (librosa.load's resampling is not reproduced)."""
-    y = audio_utilities.get_signal(str(path), expected_fs=griffin_lim.params.sampling_rate)
-    return audio_to_mel(np.asarray(y, dtype=np.float32), **kw)
+    """data.py:100-116 for a 16-bit / 32-bit PCM or float wav: loaded, resampled to 22 050 Hz like librosa.load's
+    default when the file has another rate (the reference then asserts params.sampling_rate, data.py:104)."""
+    y, sr = load(path, sr=22050, device=kw.get("device"))
+    assert sr == griffin_lim.params.sampling_rate                                                    # data.py:104
+    return audio_to_mel(y, **kw)

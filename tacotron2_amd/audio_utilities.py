@@ -54,8 +54,8 @@ def hz_to_fft_bin(f_hz, sample_rate_hz, fft_size):
     return fft_bin
 
 
-def get_signal(in_file, expected_fs=44100):
-    """Load a wav file as mono float, audio_utilities.py:117-151."""
+def _read_wav(in_file):
+    """(sample rate, mono float samples) of a 16-bit / 32-bit PCM or float32 wav file."""
     import scipy.io.wavfile
     fs, y = scipy.io.wavfile.read(in_file)
     kind = y[0].dtype
@@ -69,9 +69,15 @@ def get_signal(in_file, expected_fs=44100):
         raise Exception('8-bit PCM is not supported.')
     else:
         raise Exception('Unknown format.')
+    return fs, (y if y.ndim == 1 else y.mean(axis=1))
+
+
+def get_signal(in_file, expected_fs=44100):
+    """Load a wav file as mono float, audio_utilities.py:117-151."""
+    fs, y = _read_wav(in_file)
     if fs != expected_fs:
         raise Exception('Invalid sample rate.')
-    return y if y.ndim == 1 else y.mean(axis=1)
+    return y
 
 
 # -- tensor plumbing ------------------------------------------------------------------------

@@ -28,6 +28,41 @@ struct DeviceGuard {
 };
 
 bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+// modified Bessel function of the first kind, order 0 (power series; the Kaiser window needs x <= beta ~ 15)
+double bessel_i0(double x) {
+    double sum = 1.0, term = 1.0;
+    const double q = 0.25 * x * x;
+    for (int k = 1; k < 200; ++k) {
+        term *= q / ((double)k * (double)k);
+        sum += term;
+        if (term < 1e-18 * sum) break;
+    }
+    return sum;
+}
+
+// Right wing of resampy's 'kaiser_best' interpolation filter (resampy.filters.sinc_window): n + 1 points over
+// [0, num_zeros], rolloff * sinc(rolloff * t) tapered by the right half of a Kaiser window of 2 n + 1 points; stored
+// with the difference to the next point (interp_delta), 0 after the last.
+void resample_filter(std::vector<double>& tab) {
+    const int n = GL_RS_ZEROS * GL_RS_TABLE;
+    const double pi = 3.14159265358979323846;
+    std::vector<double> w(n + 1);
+    const double i0b = bessel_i0(GL_RS_BETA);
+    for (int j = 0; j <= n; ++j) {
+        const double t = (double)GL_RS_ZEROS * j / n;
+        const double a = pi * GL_RS_ROLLOFF * t;
+        const double sinc = j == 0 ? 1.0 : sin(a) / a;
+        const double r = (double)j / n;
+        const double kaiser = bessel_i0(GL_RS_BETA * sqrt(fmax(0.0, 1.0 - r * r))) / i0b;
+        w[j] = GL_RS_ROLLOFF * sinc * kaiser;
+    }
+    tab.resize(2 * (size_t)(n + 1));
+    for (int j = 0; j <= n; ++j) {
+        tab[2 * j] = w[j];
+        tab[2 * j + 1] = j < n ? w[j + 1] - w[j] : 0.0;
+    }
+}
 }  // namespace
 
 int gl_set_error(int code, const char* fmt, ...) {
@@ -107,10 +142,14 @@ int gl_plan_create(int n_fft, int hop, int max_frames, int max_batch, int device
     if (!rc) rc = gl_plan_alloc(p, (void**)&p->d_window_p, sizeof(float) * n_fft);
     if (!rc) rc = gl_plan_alloc(p, (void**)&p->d_tw, sizeof(float2) * n_fft);
     if (!rc) rc = gl_plan_alloc(p, (void**)&p->d_peaks, sizeof(unsigned) * (size_t)max_batch);
+    std::vector<double> rs_tab;
+    resample_filter(rs_tab);
+    if (!rc) rc = gl_plan_alloc(p, (void**)&p->d_rs_win, sizeof(double) * rs_tab.size());
     if (!rc) {
         hipError_t e = hipMemcpy(p->d_window, win.data(), sizeof(float) * n_fft, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(p->d_window_p, win_p.data(), sizeof(float) * n_fft, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(p->d_tw, tw.data(), sizeof(float2) * n_fft, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(p->d_rs_win, rs_tab.data(), sizeof(double) * rs_tab.size(), hipMemcpyHostToDevice);
         if (e != hipSuccess) rc = gl_set_error(GL_ERR_HIP, "table upload failed: %s", hipGetErrorString(e));
     }
     // Scratch and tables of every entry point of the plan's default path, now: later calls only enqueue kernels.
@@ -133,7 +172,7 @@ int gl_plan_destroy(gl_plan* p) {
     DeviceGuard guard(p->device);
     void* ptrs[] = {p->d_window, p->d_tw,     p->d_frames, p->d_xa,      p->d_xb,
                     p->d_tail_a, p->d_tail_b, p->d_fast_tab, p->d_peaks, p->d_fast_tab2, p->d_magp,
-                    p->d_inv_wsum, p->d_prev, p->d_window_p, p->d_yframes, p->d_xc, p->d_w2};
+                    p->d_inv_wsum, p->d_prev, p->d_window_p, p->d_yframes, p->d_xc, p->d_w2, p->d_rs_win};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     delete p;
@@ -274,6 +313,28 @@ int gl_wav_to_logmel(gl_plan* p, const float* y, long long y_stride, long long l
     if (rc) return rc;
     return gl_mag_to_logmel_launch(filterbank, mag, logmel, n_mels, p->n_fft / 2 + 1, B, T, clip_min,
                                    compression_factor, st);
+}
+
+long long gl_resample_length(long long n_in, int sr_in, int sr_out) {
+    if (n_in < 0 || sr_in < 1 || sr_out < 1) return 0;
+    return (long long)ceil((double)n_in * ((double)sr_out / (double)sr_in));      // librosa.resample: ceil(n * ratio)
+}
+
+int gl_resample(gl_plan* p, const float* x, long long x_stride, long long n_in, float* y, long long y_stride,
+                int sr_in, int sr_out, int B, void* stream) {
+    if (!p || !x || !y) return gl_set_error(GL_ERR_INVALID, "gl_resample: NULL argument");
+    if (sr_in < 1 || sr_out < 1) return gl_set_error(GL_ERR_INVALID, "gl_resample: sample rates must be positive");
+    if (B < 1 || B > 65535) return gl_set_error(GL_ERR_INVALID, "gl_resample: B=%d outside [1, 65535]", B);
+    const long long n_out = gl_resample_length(n_in, sr_in, sr_out);
+    if (n_in < 1 || x_stride < n_in || y_stride < n_out || n_out < 1)
+        return gl_set_error(GL_ERR_INVALID, "gl_resample: bad lengths / strides (n_in %lld, n_out %lld)", n_in, n_out);
+    const double ratio = (double)sr_out / (double)sr_in;
+    if ((int)((ratio < 1.0 ? ratio : 1.0) * GL_RS_TABLE) < 1)
+        return gl_set_error(GL_ERR_INVALID, "gl_resample: ratio %g too small for the filter table", ratio);
+    DeviceGuard guard(p->device);
+    const long long n_calc = (long long)((double)n_in * ratio);                   // resampy: int(n * ratio) samples
+    return gl_resample_launch(p, x, x_stride, n_in, y, y_stride, n_out, n_calc < n_out ? n_calc : n_out, ratio, B,
+                              (hipStream_t)stream);
 }
 
 int gl_run(gl_plan* p, const float* mag, const float* x0, float* x_out, int iters, int B, int T, void* stream) {

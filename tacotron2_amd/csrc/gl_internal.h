@@ -37,6 +37,7 @@ struct gl_plan {
     int wsum_T;         // frame count the table holds (-1: unknown)
     float* d_prev;      // [max_B][L] previous iterate for the momentum option
     float* d_window_p;  // [N] periodic Hann of the analysis path
+    double* d_rs_win;   // resampler: [GL_RS_ZEROS * GL_RS_TABLE + 1] x (filter value, difference to the next one)
     float* d_yframes;   // small problems: two sets of windowed inverse frames [2][frames][N]
     size_t yframes_bytes;
     long long bytes;
@@ -99,6 +100,13 @@ int gl_mag_to_logmel_launch(const float* fb, const float* mag, float* logmel, in
                             float clip_min, float compression_factor, hipStream_t st);
 
 // ---- misc: gl_misc.hip -------------------------------------------------------------
+// resampy 'kaiser_best': 64 zero crossings, 512 table points per crossing, Kaiser window and roll-off as below
+#define GL_RS_ZEROS 64
+#define GL_RS_TABLE 512
+#define GL_RS_BETA 14.769656459379492
+#define GL_RS_ROLLOFF 0.9475937167399596
+int gl_resample_launch(const gl_plan* p, const float* x, long long x_stride, long long n_in, float* y,
+                       long long y_stride, long long n_out, long long n_calc, double ratio, int B, hipStream_t st);
 int gl_randn_launch(float* out, long long n, uint64_t seed, long long offset, hipStream_t st);
 int gl_stitch_launch(float* out, long long out_len, const float* chunk, long long chunk_len, long long out_offset,
                      long long fade_in, long long fade_out, hipStream_t st);

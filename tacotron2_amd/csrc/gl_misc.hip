@@ -71,6 +71,53 @@ __global__ void __launch_bounds__(kThreads) k_stitch_add(float* __restrict__ out
     }
 }
 
+// ---- N3: sample-rate conversion of librosa.load (data.py:101) --------------------------------------
+// Band-limited sinc interpolation as resampy's 'kaiser_best' does it (Smith's algorithm): output sample t sits at
+// time t / ratio of the input; the filter's right wing is tabulated at num_table points per zero crossing and read
+// with linear interpolation (win + eta * delta), stepped by index_step = scale * num_table so that its cutoff
+// follows the lower of the two rates; left wing over x[n], x[n-1], ..., right wing over x[n+1], ...  One thread
+// per output sample, taps in resampy's order, weights in double, the running sum rounded to float after every
+// tap like a float32 output array.  (~2 x 64 / scale taps per sample: not a hot path, it runs once per file.)
+__global__ void __launch_bounds__(kThreads) k_resample(const float* __restrict__ x, long long x_stride, long long n_in,
+                                                       float* __restrict__ y, long long y_stride, long long n_out,
+                                                       long long n_calc, double ratio, const double2* __restrict__ win,
+                                                       int nwin, int num_table) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_out) return;
+    const float* xr = x + (long long)blockIdx.y * x_stride;
+    float* yr = y + (long long)blockIdx.y * y_stride;
+    if (t >= n_calc) {                 // librosa.util.fix_length: the one sample ceil() adds over int() is zero
+        yr[t] = 0.0f;
+        return;
+    }
+    const double scale = ratio < 1.0 ? ratio : 1.0;
+    const int index_step = (int)(scale * num_table);
+    const double time_register = (double)t * (1.0 / ratio);
+    const long long n = (long long)time_register;
+    float acc = 0.0f;
+    double frac = scale * (time_register - (double)n);
+    double index_frac = frac * num_table;
+    int offset = (int)index_frac;
+    double eta = index_frac - offset;
+    long long i_max = (nwin - offset) / index_step;
+    if (i_max > n + 1) i_max = n + 1;
+    for (long long i = 0; i < i_max; ++i) {
+        const double2 w = win[offset + i * index_step];
+        acc = (float)((double)acc + (w.x + eta * w.y) * scale * (double)xr[n - i]);
+    }
+    frac = scale - frac;
+    index_frac = frac * num_table;
+    offset = (int)index_frac;
+    eta = index_frac - offset;
+    long long k_max = (nwin - offset) / index_step;
+    if (k_max > n_in - n - 1) k_max = n_in - n - 1;
+    for (long long k = 0; k < k_max; ++k) {
+        const double2 w = win[offset + k * index_step];
+        acc = (float)((double)acc + (w.x + eta * w.y) * scale * (double)xr[n + k + 1]);
+    }
+    yr[t] = acc;
+}
+
 // ---- peak normalisation (griffin_lim.py:27-29) ---------------------------------------
 __global__ void __launch_bounds__(kThreads) k_absmax(const float* __restrict__ x, long long row_stride,
                                                      long long len, unsigned* __restrict__ peaks) {
@@ -190,6 +237,15 @@ int gl_stitch_launch(float* out, long long out_len, const float* chunk, long lon
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_stitch_add, dim3((unsigned)blocks), dim3(kThreads), 0, st, out, out_len, chunk, chunk_len,
                        out_offset, fade_in, fade_out);
+    GL_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int gl_resample_launch(const gl_plan* p, const float* x, long long x_stride, long long n_in, float* y,
+                       long long y_stride, long long n_out, long long n_calc, double ratio, int B, hipStream_t st) {
+    dim3 grid((unsigned)((n_out + kThreads - 1) / kThreads), B);
+    hipLaunchKernelGGL(k_resample, grid, dim3(kThreads), 0, st, x, x_stride, n_in, y, y_stride, n_out, n_calc, ratio,
+                       reinterpret_cast<const double2*>(p->d_rs_win), GL_RS_ZEROS * GL_RS_TABLE + 1, GL_RS_TABLE);
     GL_HIP_CHECK(hipGetLastError());
     return 0;
 }

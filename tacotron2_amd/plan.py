@@ -190,6 +190,17 @@ class Plan:
                        "gl_wav_to_logmel")
         return logmel, mag
 
+    def resample(self, y, sr_in, sr_out):
+        """y (B, n) at sr_in -> (B, ceil(n * sr_out / sr_in)) at sr_out: the conversion librosa.load applies
+        (resampy 'kaiser_best', gl_resample)."""
+        B, n = y.shape
+        n_out = int(self._lib.gl_resample_length(n, int(sr_in), int(sr_out)))
+        out = torch.empty((B, n_out), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.gl_resample(self._h, self._f32(y), n, n, self._f32(out), n_out, int(sr_in),
+                                             int(sr_out), B, _stream_ptr(self.device)), "gl_resample")
+        return out
+
     def mask_frames(self, mag, lengths):
         """Zero the rows t >= lengths[b] of mag (B, T, F) in place (ragged batches); returns the
         device int32 tensor of lengths."""

@@ -59,11 +59,17 @@ long long gl_signal_length(int n_fft, int hop, int frames);
 int gl_num_frames(int n_fft, int hop, long long len);
 
 /* Create / destroy a plan.  max_frames / max_batch bound T and B of later calls; ALL scratch and
- * tables the plan's entry points can touch are allocated here from them (signals, run tails,
- * packed magnitudes, frame buffers -- about 1.3 KB per frame-bin row at n_fft 2048: 0.8 GB for
- * 64 x 861 frames).  Window = symmetric Hann, np.hanning(N) (audio_utilities.py:88,108),
- * computed in double on the host, stored fp32.                                               */
+ * tables the plan's entry points can touch are allocated here (signals, run tails, packed
+ * magnitudes, frame buffers -- about 14 KB per frame at n_fft 2048: 0.8 GB for 64 x 861 frames).
+ * Window = symmetric Hann, np.hanning(N) (audio_utilities.py:88,108), computed in double on the
+ * host, stored fp32.  gl_plan_create sizes the scratch for max_frames * max_batch frames.
+ * gl_plan_create_capacity sizes it for max_total_frames instead (0 = max_frames * max_batch): calls
+ * then need B <= max_batch, T <= max_frames AND B * T <= max_total_frames -- one plan serves a long
+ * single utterance and a wide batch of short ones without holding memory for their product.
+ * No counterpart in the reference (numpy allocates per call, audio_utilities.py:110,175).          */
 int gl_plan_create(int n_fft, int hop, int max_frames, int max_batch, int device, gl_plan** out);
+int gl_plan_create_capacity(int n_fft, int hop, int max_frames, int max_batch, long long max_total_frames,
+                            int device, gl_plan** out);
 int gl_plan_destroy(gl_plan* plan);
 
 /* Bytes of device memory the plan currently holds (tables + scratch). */
@@ -184,7 +190,9 @@ int gl_plan_set_path(gl_plan* plan, int path);
  * With flags == 0 and momentum == 0 (the default) every entry point computes exactly what the reference
  * does.  The variants cost one extra streaming pass over x per iteration.  A configuration call: the
  * first time a variant is switched on its buffers are allocated (previous iterate; window-sum table,
- * which the data-path calls then (re)build for their frame count with a small kernel on their stream). */
+ * which the data-path calls then (re)build for their frame count with a small kernel on their stream: only
+ * when the frame count changes -- until a stream capture has recorded a call with GL_OPT_WSUM_NORMALISE on the
+ * plan; from then on every call rebuilds it, since graph replays rewrite the table unseen by the host).   */
 enum { GL_OPT_WSUM_NORMALISE = 1, GL_OPT_CLAMP_MAG = 2 };
 int gl_plan_set_options(gl_plan* plan, int flags, float momentum);
 
@@ -200,15 +208,13 @@ int gl_plan_set_run_frames(gl_plan* plan, int frames);
 
 /* north_star (d): "the full N-iteration loop kept on-device on one HIP stream, and optionally
  * hipGraph-captured".  The reference has no counterpart (its loop is a Python while,
- * audio_utilities.py:178).  gl_plan_prepare makes every lazy allocation / table upload that gl_run
- * (and gl_stft / gl_istft) of this plan could need -- since ABI 2.0 gl_plan_create / gl_plan_set_path /
- * gl_plan_set_options already do, so it only returns 0 and is kept for callers of 1.x: every data-path call
- * is legal inside a stream capture from the start.  gl_graph_begin starts capturing `stream` (non-default,
+ * audio_utilities.py:178).  gl_plan_create / gl_plan_set_path / gl_plan_set_options allocate and upload
+ * everything a plan can touch, so every data-path call is legal inside a stream capture from the start (the
+ * gl_plan_prepare of ABI 1.x / 2.x, a no-op since 2.0, is gone in 3.0).  gl_graph_begin starts capturing `stream` (non-default,
  * relaxed mode); every gl_* call enqueued on it until gl_graph_end becomes a node of the
  * graph instead of running; gl_graph_end instantiates it.  gl_graph_launch replays the whole
  * sequence (e.g. gl_mel_to_mag + gl_run(60) + gl_peak_normalise = 64 kernels) with one submission,
  * on the same buffers it was captured with.  Plan settings (path, run length) are frozen in.       */
-int gl_plan_prepare(gl_plan* plan);
 int gl_graph_begin(void* stream);
 int gl_graph_end(void* stream, gl_graph** out);
 int gl_graph_launch(gl_graph* graph, void* stream);

@@ -24,6 +24,8 @@ SIGNATURES = {
     "gl_num_frames": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_longlong]),
     "gl_plan_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                       ctypes.POINTER(_plan_p)]),
+    "gl_plan_create_capacity": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                               ctypes.c_longlong, ctypes.c_int, ctypes.POINTER(_plan_p)]),
     "gl_plan_destroy": (ctypes.c_int, [_plan_p]),
     "gl_plan_device_bytes": (ctypes.c_longlong, [_plan_p]),
     "gl_plan_set_path": (ctypes.c_int, [_plan_p, ctypes.c_int]),
@@ -49,7 +51,6 @@ SIGNATURES = {
     "gl_resample_length": (ctypes.c_longlong, [ctypes.c_longlong, ctypes.c_int, ctypes.c_int]),
     "gl_resample": (ctypes.c_int, [_plan_p, _c_float_p, ctypes.c_longlong, ctypes.c_longlong, _c_float_p,
                                    ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
-    "gl_plan_prepare": (ctypes.c_int, [_plan_p]),
     "gl_graph_begin": (ctypes.c_int, [ctypes.c_void_p]),
     "gl_graph_end": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]),
     "gl_graph_launch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),

@@ -87,7 +87,7 @@ int gl_plan_alloc(gl_plan* p, void** ptr, size_t bytes) {
 
 extern "C" {
 
-int gl_version(void) { return 201; }
+int gl_version(void) { return 300; }
 
 const char* gl_last_error(void) { return g_err; }
 
@@ -99,6 +99,11 @@ int gl_num_frames(int n_fft, int hop, long long len) {
 }
 
 int gl_plan_create(int n_fft, int hop, int max_frames, int max_batch, int device, gl_plan** out) {
+    return gl_plan_create_capacity(n_fft, hop, max_frames, max_batch, 0, device, out);
+}
+
+int gl_plan_create_capacity(int n_fft, int hop, int max_frames, int max_batch, long long max_total_frames, int device,
+                            gl_plan** out) {
     if (!out) return gl_set_error(GL_ERR_INVALID, "gl_plan_create: out is NULL");
     *out = nullptr;
     if (!is_pow2(n_fft) || n_fft < 64 || n_fft > 4096)
@@ -107,6 +112,10 @@ int gl_plan_create(int n_fft, int hop, int max_frames, int max_batch, int device
     if (max_frames < 1 || max_batch < 1 || max_batch > 65535)
         return gl_set_error(GL_ERR_INVALID, "max_frames must be >= 1 and max_batch in [1, 65535] (got %d, %d)",
                             max_frames, max_batch);
+    const long long full = (long long)max_frames * max_batch;
+    if (max_total_frames < 0 || max_total_frames > full)
+        return gl_set_error(GL_ERR_INVALID, "max_total_frames must be in [0, max_frames * max_batch = %lld], got %lld", full,
+                            max_total_frames);
     int ndev = 0;
     GL_HIP_CHECK(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev)
@@ -121,6 +130,7 @@ int gl_plan_create(int n_fft, int hop, int max_frames, int max_batch, int device
     p->hop = hop;
     p->max_T = max_frames;
     p->max_B = max_batch;
+    p->cap_frames = max_total_frames > 0 ? max_total_frames : full;
     p->device = device;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) p->n_cu = prop.multiProcessorCount;
@@ -207,20 +217,25 @@ int gl_plan_set_options(gl_plan* p, int flags, float momentum) {
     DeviceGuard guard(p->device);
     const int N = p->n_fft;
     if (momentum != 0.0f && !p->d_prev) {
-        int rc = gl_plan_alloc(p, (void**)&p->d_prev, (size_t)p->max_B * gl_len(N, p->hop, p->max_T) * sizeof(float));
+        int rc = gl_plan_alloc(p, (void**)&p->d_prev, gl_signal_floats(p) * sizeof(float));
         if (rc) return rc;
     }
-    if ((flags & GL_OPT_WSUM_NORMALISE) && !p->d_inv_wsum) {
+    if ((flags & GL_OPT_WSUM_NORMALISE) && !(p->d_w2 && p->d_inv_wsum && p->w2_uploaded)) {
+        // each step is guarded on its own, so a call that failed half way (an allocation, the upload) is completed
+        // by the next one instead of leaking a buffer or leaving d_w2 unwritten
         std::vector<double> w2(N);
         const double pi = 3.14159265358979323846;
         for (int n = 0; n < N; ++n) {
             const double w = 0.5 - 0.5 * cos(2.0 * pi * n / (double)(N - 1));
             w2[n] = w * w;
         }
-        int rc = gl_plan_alloc(p, (void**)&p->d_w2, sizeof(double) * N);
-        if (!rc) rc = gl_plan_alloc(p, (void**)&p->d_inv_wsum, (size_t)gl_len(N, p->hop, p->max_T) * sizeof(float));
+        int rc = 0;
+        if (!p->d_w2) rc = gl_plan_alloc(p, (void**)&p->d_w2, sizeof(double) * N);
+        if (!rc && !p->d_inv_wsum)
+            rc = gl_plan_alloc(p, (void**)&p->d_inv_wsum, (size_t)gl_len(N, p->hop, p->max_T) * sizeof(float));
         if (rc) return rc;
         GL_HIP_CHECK(hipMemcpy(p->d_w2, w2.data(), sizeof(double) * N, hipMemcpyHostToDevice));
+        p->w2_uploaded = 1;
         p->wsum_T = -1;
     }
     p->opt_flags = flags;
@@ -232,6 +247,9 @@ static int check_call(const gl_plan* p, int B, int T, const char* who) {
     if (!p) return gl_set_error(GL_ERR_INVALID, "%s: plan is NULL", who);
     if (B < 1 || B > p->max_B) return gl_set_error(GL_ERR_INVALID, "%s: B=%d outside [1, %d]", who, B, p->max_B);
     if (T < 1 || T > p->max_T) return gl_set_error(GL_ERR_INVALID, "%s: T=%d outside [1, %d]", who, T, p->max_T);
+    if ((long long)B * T > p->cap_frames)
+        return gl_set_error(GL_ERR_INVALID, "%s: B*T = %lld frames beyond the plan's capacity of %lld", who,
+                            (long long)B * T, p->cap_frames);
     return 0;
 }
 
@@ -385,13 +403,6 @@ int gl_mel_run(gl_plan* p, const float* filterbank, const float* mel, int n_mels
         if (rc) return rc;
     }
     return gl_fast_run_packed(p, x0, x_out, iters, B, T, st);
-}
-
-int gl_plan_prepare(gl_plan* p) {
-    if (!p) return gl_set_error(GL_ERR_INVALID, "gl_plan_prepare: plan is NULL");
-    // kept for ABI compatibility: since version 2.0 gl_plan_create, gl_plan_set_path and gl_plan_set_options
-    // allocate everything their plan can touch, so there is nothing left to front-load
-    return 0;
 }
 
 struct gl_graph {

@@ -205,24 +205,25 @@ long long gl_fast_small_form_limit(const gl_plan* p) {
 // inside a stream capture).
 int gl_fast_alloc(gl_plan* p) {
     const int N = p->n_fft, H = p->hop;
-    const size_t xbytes = (size_t)p->max_B * gl_len(N, H, p->max_T) * sizeof(float);
+    const size_t xbytes = gl_signal_floats(p) * sizeof(float);
     int rc = gl_plan_alloc(p, (void**)&p->d_xa, xbytes);
     if (!rc) rc = gl_plan_alloc(p, (void**)&p->d_xb, xbytes);
     if (!rc) rc = build_table2(p);
     if (!rc && N == 1024) rc = gl_plan_alloc(p, (void**)&p->d_xc, xbytes);      // read / write / clear rotation
     if (!rc && N == kN) {
-        // run tails: at most ceil(max_T / g_min) runs per utterance
+        // run tails, [B][runs][N-H] dense: a run has at least g_min frames unless it is its utterance's only or last
+        // one, so a call has at most B * T / g_min + B <= cap_frames / g_min + max_B runs
         int g_min = (N - H + H - 1) / H;
         if (g_min < 1) g_min = 1;
-        const size_t max_runs = (size_t)(p->max_T + g_min - 1) / g_min;
-        const size_t tbytes = (size_t)p->max_B * max_runs * (size_t)(N - H) * sizeof(float);
+        const size_t max_runs = (size_t)(p->cap_frames / g_min) + (size_t)p->max_B + 1;
+        const size_t tbytes = max_runs * (size_t)(N - H) * sizeof(float);
         rc = gl_plan_alloc(p, (void**)&p->d_tail_a, tbytes);
         if (!rc) rc = gl_plan_alloc(p, (void**)&p->d_tail_b, tbytes);
         if (!rc) rc = build_table1(p);
         if (!rc && gl_fast_regring_hop(p))
-            rc = gl_plan_alloc(p, (void**)&p->d_magp, (size_t)p->max_B * p->max_T * kMagPack * sizeof(float));
+            rc = gl_plan_alloc(p, (void**)&p->d_magp, (size_t)p->cap_frames * kMagPack * sizeof(float));
     }
-    long long fr = (long long)p->max_B * p->max_T;
+    long long fr = p->cap_frames;
     if (fr > gl_fast_small_form_limit(p)) fr = gl_fast_small_form_limit(p);
     if (!rc && fr > 0) {                                   // two sets of windowed inverse frames
         p->yframes_bytes = (size_t)2 * fr * N * sizeof(float);
@@ -262,17 +263,20 @@ int gl_post_iter(gl_plan* p, const float* x_main, const float* tail, float* out,
 
 // The window-sum table of the normalised inverse STFT depends on the frame count of the call: (re)built on the
 // call's own stream by a small kernel whenever T differs from the table's.  Inside a stream capture the build is
-// always recorded (it then belongs to the graph) and the cached T is forgotten, because nothing has run yet.
+// always recorded (it then belongs to the graph), and from then on EVERY call enqueues it: a replay of that graph
+// rewrites the table for the captured T without the host seeing it, so the cached frame count can no longer be
+// trusted (capture T1 / eager T2 / replay / eager T2 would otherwise normalise with T1's sums).
 int gl_wsum_enqueue(gl_plan* p, int T, hipStream_t st) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (st) (void)hipStreamIsCapturing(st, &cs);
     const bool capturing = cs != hipStreamCaptureStatusNone;
-    if (!capturing && p->wsum_T == T) return 0;
+    if (capturing) p->wsum_captured = 1;
+    if (!p->wsum_captured && p->wsum_T == T) return 0;
     const long long L = gl_len(p->n_fft, p->hop, T);
     hipLaunchKernelGGL(k_build_inv_wsum, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, st, p->d_w2, p->d_inv_wsum, L,
                        p->n_fft, p->hop, T);
     GL_HIP_CHECK(hipGetLastError());
-    p->wsum_T = capturing ? -1 : T;
+    p->wsum_T = T;
     return 0;
 }
 

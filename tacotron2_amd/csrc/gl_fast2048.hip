@@ -505,8 +505,40 @@ __global__ void __launch_bounds__(64 * kRRWaves, 1) k_gl2048_regring(AlignedArgs
         for (int jj = 0; jj < HS; ++jj) xraw[OVR + jj] = xn[jj] + xt[jj];
     };
     // the HS finished rows of frame n leave; the accumulator slides
+#if defined(GL_EXPERIMENT) && defined(GL_PAR)
+    // parity attribution build GL_PAR & 4: overlap-add in two-float arithmetic (exact product by fma, TwoSum into a
+    // low-order accumulator that joins the sum when the row leaves); spills, timing is meaningless
+    v2f accl[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) accl[j] = (v2f){0.0f, 0.0f};
+    auto ola_add = [&](int j, v2f z, v2f w) {
+        if (GL_PAR & 4) {
+            const v2f pr = z * w;
+            const v2f pe = __builtin_elementwise_fma(z, w, -pr);
+            const v2f sum = accr[j] + pr;
+            const v2f bb = sum - accr[j];
+            const v2f err = (accr[j] - (sum - bb)) + (pr - bb);
+            accr[j] = sum;
+            accl[j] += err + pe;
+        } else {
+            accr[j] = __builtin_elementwise_fma(z, w, accr[j]);
+        }
+    };
+#else
+    auto ola_add = [&](int j, v2f z, v2f w) { accr[j] = __builtin_elementwise_fma(z, w, accr[j]); };
+#endif
     auto store_rows = [&](int n) {
         float* orow = p.x_out + (long long)b * p.L + (long long)n * H + 2 * l;
+#if defined(GL_EXPERIMENT) && defined(GL_PAR)
+        if (GL_PAR & 4) {
+#pragma unroll
+            for (int jj = 0; jj < HS; ++jj) accr[jj] += accl[jj];
+#pragma unroll
+            for (int j = 0; j < OVR; ++j) accl[j] = accl[j + HS];
+#pragma unroll
+            for (int jj = 0; jj < HS; ++jj) accl[OVR + jj] = (v2f){0.0f, 0.0f};
+        }
+#endif
 #pragma unroll
         for (int jj = 0; jj < HS; ++jj) *reinterpret_cast<v2f*>(orow + 128 * jj) = accr[jj];
 #pragma unroll
@@ -561,7 +593,7 @@ __global__ void __launch_bounds__(64 * kRRWaves, 1) k_gl2048_regring(AlignedArgs
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const v2f w = tb.get(kT2Win + j);
-            accr[j] = __builtin_elementwise_fma(zB[j], w, accr[j]);
+            ola_add(j, zB[j], w);
             zB[j] = zA[j];
             zA[j] = (j == 0) ? __builtin_elementwise_fma(xraw[0], w, nudge) : xraw[j] * w;
         }
@@ -571,7 +603,7 @@ __global__ void __launch_bounds__(64 * kRRWaves, 1) k_gl2048_regring(AlignedArgs
         middle_project2(zB, mm, m512, tb);
         fft_inverse_1024(zB, ex, l, kloB, tb, st);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) accr[j] = __builtin_elementwise_fma(zB[j], tb.get(kT2Win + j), accr[j]);
+        for (int j = 0; j < 16; ++j) ola_add(j, zB[j], tb.get(kT2Win + j));
         store_rows(f1 - 1);
     }
     // partial sums of the N-H samples after the run's last frame

@@ -142,6 +142,19 @@ __device__ __forceinline__ void project2(v2f& X, v2f& Y, v2f m2) {
     v2f rs;
     rs.x = __builtin_amdgcn_rsqf(rx);
     rs.y = __builtin_amdgcn_rsqf(ry);
+#if defined(GL_EXPERIMENT) && defined(GL_PAR)
+    // parity attribution builds (abl/build.sh par* -DGL_EXPERIMENT -DGL_PAR=n; tools_parity_distribution.py --lib):
+    // 1 = one Newton step on v_rsq_f32 (1 ulp -> correctly rounded to within the step's own rounding)
+    // 2 = IEEE square root and division instead of v_rsq_f32
+    if (GL_PAR & 1) {
+        rs.x = rs.x * fmaf(-0.5f * rx, rs.x * rs.x, 1.5f);
+        rs.y = rs.y * fmaf(-0.5f * ry, rs.y * rs.y, 1.5f);
+    }
+    if (GL_PAR & 2) {
+        rs.x = __fdiv_rn(1.0f, __fsqrt_rn(rx));
+        rs.y = __fdiv_rn(1.0f, __fsqrt_rn(ry));
+    }
+#endif
     const v2f sc = m2 * rs;
     X = X * sc.xx;
     Y = Y * sc.yy;

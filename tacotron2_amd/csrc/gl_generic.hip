@@ -233,8 +233,8 @@ __global__ void __launch_bounds__(kThreads) k_generic_ola(const float* __restric
 // geometries the fused kernels do not cover completely, gl_plan_set_path(1) otherwise)
 int gl_generic_alloc(gl_plan* p) {
     int rc = 0;
-    if (!p->d_frames) rc = gl_plan_alloc(p, (void**)&p->d_frames, (size_t)p->max_B * p->max_T * p->n_fft * sizeof(float));
-    const size_t bytes = (size_t)p->max_B * gl_len(p->n_fft, p->hop, p->max_T) * sizeof(float);
+    if (!p->d_frames) rc = gl_plan_alloc(p, (void**)&p->d_frames, (size_t)p->cap_frames * p->n_fft * sizeof(float));
+    const size_t bytes = gl_signal_floats(p) * sizeof(float);
     if (!rc && !p->d_xa) rc = gl_plan_alloc(p, (void**)&p->d_xa, bytes);
     if (!rc && !p->d_xb) rc = gl_plan_alloc(p, (void**)&p->d_xb, bytes);
     return rc;

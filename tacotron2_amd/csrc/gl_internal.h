@@ -11,6 +11,7 @@ struct gl_plan {
     int hop;          // H
     int max_T;
     int max_B;
+    long long cap_frames;   // calls need B * T <= cap_frames: every frame-proportional buffer is sized from it
     int device;
     int path;         // 0 auto, 1 generic
     int run_frames;   // frames per wave-run of the fused kernels; 0 = choose from (B, T)
@@ -20,22 +21,24 @@ struct gl_plan {
     // Everything below is allocated by gl_plan_create (what the plan's default path can touch), by
     // gl_plan_set_path(1) (generic scratch of a plan whose geometry has fused kernels) or by gl_plan_set_options
     // (the variants' buffers) -- never by gl_run / gl_stft / gl_istft, which only enqueue work.
-    float* d_frames;  // generic path scratch [max_B][max_T][N]
-    float* d_xa;      // ping-pong signal buffers [max_B][L]
+    float* d_frames;  // generic path scratch [cap_frames][N]
+    float* d_xa;      // ping-pong signal buffers, gl_signal_floats() each
     float* d_xb;
     float* d_xc;      // third signal buffer of the n_fft-1024 run kernel (read / write / clear rotation)
     float* d_tail_a;  // n_fft 2048 fused kernels: per-run partial-sum tails
     float* d_tail_b;
     float* d_fast_tab;  // constant table of k_fast2048
     float* d_fast_tab2; // constant table of the register-FFT kernels
-    float* d_magp;      // register-ring kernel: magnitudes repacked per lane [max_B][max_T][1088]
+    float* d_magp;      // register-ring kernel: magnitudes repacked per lane [cap_frames][1088]
     unsigned* d_peaks;  // [max_B] bit patterns of max|x|
     int opt_flags;      // GL_OPT_* (gl_plan_set_options)
     float momentum;     // fast Griffin-Lim extrapolation factor, 0 = off
     double* d_w2;       // [N] squared window in double (window-sum option)
     float* d_inv_wsum;  // [L(max_T)] 1 / sum_t w^2(s - tH), rebuilt on the call's stream when T changes
     int wsum_T;         // frame count the table holds (-1: unknown)
-    float* d_prev;      // [max_B][L] previous iterate for the momentum option
+    int wsum_captured;  // a stream capture has recorded a table build: replays rewrite the table behind the host's back
+    int w2_uploaded;    // d_w2 holds the squared window
+    float* d_prev;      // gl_signal_floats(): previous iterate for the momentum option
     float* d_window_p;  // [N] periodic Hann of the analysis path
     double* d_rs_win;   // resampler: [GL_RS_ZEROS * GL_RS_TABLE + 1] x (filter value, difference to the next one)
     float* d_yframes;   // small problems: two sets of windowed inverse frames [2][frames][N]
@@ -56,6 +59,11 @@ int gl_set_error(int code, const char* fmt, ...);
     } while (0)
 
 static inline long long gl_len(int N, int H, int T) { return (long long)T * H + N; }
+// floats of one plan-owned signal buffer [B][L]: B * L = (B * T) * H + B * N <= cap_frames * H + min(max_B, cap_frames) * N
+static inline size_t gl_signal_floats(const gl_plan* p) {
+    const long long b = p->max_B < p->cap_frames ? p->max_B : p->cap_frames;
+    return (size_t)(p->cap_frames * p->hop + b * p->n_fft);
+}
 int gl_plan_alloc(gl_plan* p, void** ptr, size_t bytes);  // tracked hipMalloc
 
 // ---- generic (any power-of-two N) kernels: gl_generic.hip ---------------------

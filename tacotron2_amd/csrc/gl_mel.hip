@@ -26,14 +26,15 @@ constexpr int kTileF = 32 * kNJ;
 // PACKED output (gl_mel_run): the register-ring Griffin-Lim kernels read a frame's magnitudes as [quad q][lane][4] =
 // (m[k], m[1024-k]) of the lane's mirror pairs u = 2q, 2q+1, then 64 copies of m[512], pre-scaled by 1/2048
 // (gl_fast2048.hip, k_mag_repack).  A tile is then 32 lanes x one quad = FOUR accumulators whose registers are the
-// four floats of one 16-byte store; 2 lane halves x 4 quads + 1 tile of bin 512 = 9 tiles of 128 columns.
+// four floats of one 16-byte store; 2 lane halves x 4 quads = 8 tiles of 128 columns.  Bin 512 is ONE column: the
+// eight tiles of a frame group take turns at it (a fifth accumulator pass with the column broadcast over the 32
+// MFMA columns, 33 column blocks of work for the 33 that exist; a ninth tile of its own did 36).
 constexpr int kNJPacked = 4;
-constexpr int kPackedTiles = 9;
+constexpr int kPackedTiles = 8;
 constexpr int kPackRow = 1088;  // floats per packed frame (gl_fft1024.h: kMagPack)
 constexpr float kPackScale = 1.0f / 2048.0f;
 // bin of column c (0..3) of lane-column jj (0..31) of packed tile ft
 __device__ __forceinline__ int packed_bin(int ft, int jj, int c) {
-    if (ft == kPackedTiles - 1) return 512;
     const int l = 32 * (ft & 1) + jj, u = 2 * (ft >> 1) + (c >> 1);
     const int k = l ? l + 128 * u : (u < 4 ? 128 * u : 64 + 128 * (u - 4));   // lane 0 owns the multiples of 64
     return (c & 1) ? 1024 - k : k;
@@ -95,7 +96,9 @@ k_mel_to_mag(const float* __restrict__ fb, const float* __restrict__ mel, float*
     const int g_step = n_slots * 8;
 
     __shared__ __attribute__((aligned(16))) v4f Bs[kKC][32];
+    __shared__ float Bs512[kKC];                       // PACKED: column 512 of the filterbank
     auto stage_b = [&](int kc) {
+        if (PACKED && threadIdx.x < kKC) Bs512[threadIdx.x] = kc + (int)threadIdx.x < K ? fb[(long long)(kc + threadIdx.x) * F + 512] : 0.0f;
         for (int e = threadIdx.x; e < kKC * 32; e += 64 * kWaves) {
             const int k = e >> 5, jj = e & 31;
             const bool k_ok = kc + k < K;
@@ -163,22 +166,20 @@ k_mel_to_mag(const float* __restrict__ fb, const float* __restrict__ mel, float*
         if constexpr (PACKED) {
             // registers r of the four accumulators = the quad (m[k], m[1024-k], m[k'], m[1024-k']) of lane
             // 32 (ft & 1) + li for frame t0 + row(r): one 16-byte store, 512 contiguous bytes per half-wave
-            const bool m512 = ft == kPackedTiles - 1;                 // 64 copies of bin 512: lanes li < 16 store
-            float* base = mag + ((long long)b * T + t0) * kPackRow + (m512 ? 1024 : (ft >> 1) * 256 + (ft & 1) * 128);
+            float* base = mag + ((long long)b * T + t0) * kPackRow + (ft >> 1) * 256 + (ft & 1) * 128;
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, kRsrcBytes, kRsrcFlags);
             const int lane_off = (4 * lk * kPackRow + 4 * li) * 4;
             const int t_end = frames ? min(frames[b], T) : T;         // rows from t_end on are written as zeros
-            if (m512 && li >= 16) return;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ro = (r & 3) + 8 * (r >> 2);
                 const int t = t0 + ro + 4 * lk;
                 if (t >= T) continue;
-                const float live = t < t_end ? kPackScale : 0.0f;
-                typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                const bool live = t < t_end;     // a select, not a product: padding rows are exact zeros whatever the
+                typedef unsigned v4u __attribute__((ext_vector_type(4)));   // decoder left there (inf * 0 would be NaN)
                 v4f v;
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) v[j] = fmaxf(acc[j][r], floor_val) * live;
+                for (int j = 0; j < NJ; ++j) v[j] = live ? fmaxf(acc[j][r], floor_val) * kPackScale : 0.0f;
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), rs, lane_off, ro * kPackRow * 4, 0);
             }
             return;
@@ -213,6 +214,36 @@ k_mel_to_mag(const float* __restrict__ fb, const float* __restrict__ mel, float*
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
     };
 
+    // PACKED: bin 512 of the group's frames, 64 copies each at [1024, 1088) of the packed row.  All 32 MFMA columns
+    // carry the same filterbank column, so every lane of a half-wave holds m[512] of its register's frame and
+    // lanes li < 16 store four copies each (256 contiguous bytes per frame).
+    auto mfma_512 = [&](f32x16& a5, const float (&av)[kKC / 2], int kend) {
+#pragma unroll
+        for (int s = 0; s < kKC / 2; ++s)
+            if (FULLK || 2 * s < kend) a5 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], Bs512[2 * s + lk], a5, 0, 0, 0);
+    };
+    auto store_512 = [&](int g, const f32x16& a5) {
+        const int b = g / n_tblocks;
+        const int t0 = ((g - b * n_tblocks) * kWaves + wave) * kTileT;
+        if (t0 >= T || li >= 16) return;
+        float* base = mag + ((long long)b * T + t0) * kPackRow + 1024;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, kRsrcBytes, kRsrcFlags);
+        const int lane_off = (4 * lk * kPackRow + 4 * li) * 4;
+        const int t_end = frames ? min(frames[b], T) : T;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ro = (r & 3) + 8 * (r >> 2);
+            const int t = t0 + ro + 4 * lk;
+            if (t >= T) continue;
+            typedef unsigned v4u __attribute__((ext_vector_type(4)));
+            const float m = t < t_end ? fmaxf(a5[r], floor_val) * kPackScale : 0.0f;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, (v4f){m, m, m, m}), rs, lane_off,
+                                                   ro * kPackRow * 4, 0);
+        }
+    };
+    // the tiles of one (slot, XCD) walk the same groups: the one whose turn it is on this step takes bin 512
+    int turn = (slot + (id & 7)) % kPackedTiles;
+
     if (FULLK) {
         stage_b(0);
         __syncthreads();
@@ -223,11 +254,24 @@ k_mel_to_mag(const float* __restrict__ fb, const float* __restrict__ mel, float*
             zero(acc);
             mfma_chunk(acc, av, K);
             store(g, acc);
+            if constexpr (PACKED) {
+                if (turn == ft) {                    // workgroup-uniform
+                    f32x16 a5;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) a5[r] = 0.0f;
+                    mfma_512(a5, av, K);
+                    store_512(g, a5);
+                }
+                turn = turn + 1 == kPackedTiles ? 0 : turn + 1;
+            }
         }
     } else {
         for (int g = g_first; g < n_groups; g += g_step) {   // workgroup-uniform trip count
             f32x16 acc[NJ];
             zero(acc);
+            f32x16 a5;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a5[r] = 0.0f;
             for (int kc = 0; kc < K; kc += kKC) {
                 float av[kKC / 2];
                 load_a(g, kc, av);
@@ -235,8 +279,13 @@ k_mel_to_mag(const float* __restrict__ fb, const float* __restrict__ mel, float*
                 stage_b(kc);
                 __syncthreads();
                 mfma_chunk(acc, av, min(kKC, K - kc));
+                if (PACKED && turn == ft) mfma_512(a5, av, min(kKC, K - kc));
             }
             store(g, acc);
+            if constexpr (PACKED) {
+                if (turn == ft) store_512(g, a5);
+                turn = turn + 1 == kPackedTiles ? 0 : turn + 1;
+            }
         }
     }
 }

@@ -114,7 +114,7 @@ def mel_to_audio(mel_spectrogram, *, basis=None, n_fft=None, hop=None, iteration
         plan.peak_normalise(x, mode=1)
     elif normalize is not None:
         raise ValueError("normalize must be 'reference', 'peak' or None")
-    return x, mag
+    return x, (mag if return_mag else None)
 
 
 def logmel_to_audio(y_pred_post, *, compression_factor=1.0, basis=None, n_fft=None, hop=None, iterations=None,
@@ -171,7 +171,7 @@ def logmel_to_audio(y_pred_post, *, compression_factor=1.0, basis=None, n_fft=No
         plan.peak_normalise(x, mode=1)
     elif normalize is not None:
         raise ValueError("normalize must be 'reference', 'peak' or None")
-    return x, mag
+    return x, (mag if return_mag else None)
 
 
 def infer_to_wav(y_pred_post, filenames=None, **kw):

@@ -31,20 +31,24 @@ def _require_gpu(device):
 class Plan:
     """Owns a gl_plan handle.  Methods take/return fp32 torch tensors on the plan's device."""
 
-    def __init__(self, n_fft, hop, max_frames, max_batch, device=None):
+    def __init__(self, n_fft, hop, max_frames, max_batch, device=None, max_total_frames=None):
+        """max_total_frames: frames (B * T) the plan's scratch is sized for; None = max_frames * max_batch.  A call
+        needs T <= max_frames, B <= max_batch and B * T <= max_total_frames (gl_plan_create_capacity)."""
         self.device = _require_gpu(device)
         self.n_fft = int(n_fft)
         self.hop = int(hop)
         self.max_frames = int(max_frames)
         self.max_batch = int(max_batch)
+        self.max_total_frames = self.max_frames * self.max_batch if max_total_frames is None else int(max_total_frames)
         self.n_bins = self.n_fft // 2 + 1
         self._h = ctypes.c_void_p()
         self._lib = _lib.lib()
         self._path = 0            # plan defaults; Plan.run(path=..., run_frames=...) overrides them for ONE call
         self._run_frames = 0
         self._shared = False      # True for plans handed out by get_plan(): their defaults are frozen
-        _lib.check(self._lib.gl_plan_create(self.n_fft, self.hop, self.max_frames, self.max_batch,
-                                            self.device.index, ctypes.byref(self._h)), "gl_plan_create")
+        _lib.check(self._lib.gl_plan_create_capacity(self.n_fft, self.hop, self.max_frames, self.max_batch,
+                                                     self.max_total_frames, self.device.index,
+                                                     ctypes.byref(self._h)), "gl_plan_create_capacity")
 
     # -- lifetime ---------------------------------------------------------------
     def close(self):
@@ -304,11 +308,6 @@ class Plan:
 
 
     # -- hipGraph capture ---------------------------------------------------------------
-    def prepare(self):
-        """Make every lazy allocation of the Griffin-Lim path now (needed before capture())."""
-        with torch.cuda.device(self.device):
-            _lib.check(self._lib.gl_plan_prepare(self._h), "gl_plan_prepare")
-
     def capture(self):
         """Context manager: the plan calls made inside are recorded into a hipGraph instead of
         running (all tensors, outputs included, must exist beforehand: pass out=...).
@@ -349,7 +348,6 @@ class _Capture:
 
     def __enter__(self):
         p = self.plan
-        p.prepare()
         self._side = torch.cuda.Stream(device=p.device)
         self._side.wait_stream(torch.cuda.current_stream(p.device))
         self._ctx = torch.cuda.stream(self._side)
@@ -375,18 +373,22 @@ _cache_lock = threading.Lock()
 
 
 def get_plan(n_fft, hop, frames, batch, device=None):
-    """Cached plan for (n_fft, hop, device), regrown when frames/batch exceed its bounds."""
+    """Cached plan for (n_fft, hop, device), regrown when a call exceeds its bounds.  The scratch is sized from
+    the largest frame TOTAL (batch * frames) any call has asked for, not from max(frames) x max(batch): one long
+    utterance followed by a wide batch of short ones holds memory for the larger of the two, not their product."""
     dev = _require_gpu(device)
     key = (int(n_fft), int(hop), dev.index)
+    frames, batch = int(frames), int(batch)
     with _cache_lock:
         p = _cache.get(key)
-        if p is None or p.max_frames < frames or p.max_batch < batch:
-            mf = max(int(frames), p.max_frames if p else 0)
-            mb = max(int(batch), p.max_batch if p else 0)
+        if p is None or p.max_frames < frames or p.max_batch < batch or p.max_total_frames < frames * batch:
+            mf = max(frames, p.max_frames if p else 0)
+            mb = max(batch, p.max_batch if p else 0)
+            cap = max(frames * batch, p.max_total_frames if p else 0)
             if p is not None:
                 torch.cuda.synchronize(dev)
                 p.close()
-            p = Plan(n_fft, hop, mf, mb, dev)
+            p = Plan(n_fft, hop, mf, mb, dev, max_total_frames=cap)
             p._shared = True
             _cache[key] = p
         return p

@@ -30,12 +30,15 @@ def shard_batch(batch, world_size=None, rank=None, group=None):
     return batch[lo:hi]
 
 
-def gather_waveforms(local, n_total, group=None):
+def gather_waveforms(local, n_total, group=None, always_collective=False):
     """All-gather per-rank waveforms (n_local, L) into (n_total, L) in batch order.
 
     Shards may differ by one utterance, so every rank pads to the largest shard; the padding is
-    dropped after the gather.  Returns the full tensor on every rank."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    dropped after the gather.  Returns the full tensor on every rank.  A group of one rank returns
+    `local` without communicating unless always_collective asks for the all_gather anyway (a one-GPU
+    box can then exercise the RCCL path: init, stream ordering against the library's stream, the
+    padded gather)."""
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not always_collective):
         return local
     world = dist.get_world_size(group)
     max_local = (n_total + world - 1) // world
@@ -51,9 +54,9 @@ def gather_waveforms(local, n_total, group=None):
     return torch.cat(out, dim=0)
 
 
-def reconstruct_sharded(mels, reconstruct_fn, gather=True, group=None):
+def reconstruct_sharded(mels, reconstruct_fn, gather=True, group=None, always_collective=False):
     """Run `reconstruct_fn(local_mels) -> (n_local, L) tensor` on this rank's shard of `mels`
     (B, n_mels, T) and optionally gather the waveforms of the whole batch."""
     n_total = len(mels)
     local = reconstruct_fn(shard_batch(mels, group=group))
-    return gather_waveforms(local, n_total, group) if gather else local
+    return gather_waveforms(local, n_total, group, always_collective) if gather else local

@@ -152,21 +152,23 @@ def cpu_baseline_all_cores(N, H, T, iters, budget_s, per_utt_s):
 
 def traffic_for(lib_path, default_cfg, fused):
     """HBM bytes per launch of the dominant kernel from the PMC passes (FETCH_SIZE x2 gfx950 correction +
-    WRITE_SIZE, separate rocprofv3 --pmc runs of this same command; tools_pmc_mem.sh).  A stored measurement:
-    it is stamped only on the headline workload and only when it was taken with the very library this run
-    loaded (sha256 recorded beside it); otherwise null with the reason."""
-    tpath = os.path.join(ROOT, "profiles", "r2_traffic.json")
+    WRITE_SIZE, separate rocprofv3 --pmc runs of this same command; tools_pmc_mem.sh), and the MFMA counters of the
+    mel inversion on the bench path (tools_pmc_k1.sh).  Stored measurements: they are stamped only on the headline
+    workload and only when they were taken with the very library this run loaded (sha256 recorded beside them);
+    otherwise null with the reason.  Returns (traffic, note, k1 record or None)."""
+    tpath = os.path.join(ROOT, "profiles", "r3_traffic.json")
     if not (default_cfg and fused):
-        return None, "only measured for the headline workload on the fused path"
+        return None, "only measured for the headline workload on the fused path", None
     if not os.path.exists(tpath):
-        return None, "profiles/r2_traffic.json absent"
+        return None, "profiles/r3_traffic.json absent", None
     with open(tpath) as fh:
         rec = json.load(fh)
     sha = file_sha256(lib_path)
     if rec.get("lib_sha256") != sha:
-        return None, (f"profiles/r2_traffic.json was measured with libgl_hip.so sha256 {str(rec.get('lib_sha256'))[:12]}..., "
-                      f"this run loaded {sha[:12]}...: not stamped")
-    return rec.get("hbm_bytes_per_launch"), f"rocprofv3 PMC passes of this library (sha256 {sha[:12]}..., git {rec.get('git_head', '?')[:9]})"
+        return None, (f"profiles/r3_traffic.json was measured with libgl_hip.so sha256 {str(rec.get('lib_sha256'))[:12]}..., "
+                      f"this run loaded {sha[:12]}...: not stamped"), None
+    note = f"rocprofv3 PMC passes of this library (sha256 {sha[:12]}..., git {rec.get('git_head', '?')[:9]})"
+    return rec.get("hbm_bytes_per_launch"), note, rec.get("k1")
 
 
 def _events_ms(fn, reps):
@@ -369,10 +371,23 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29581")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_dev))
-        else:
-            dist.init_process_group(backend)
+        # RCCL prints a version banner on STDOUT when its communicator comes up; the contract is ONE JSON line there,
+        # so stdout points at stderr until the first collective has run
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_dev))
+            else:
+                dist.init_process_group(backend)
+            dist.barrier()
+            if backend == "nccl":
+                torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
     else:
         # the all-cores CPU leg starts child processes: run it before this process touches the GPU
         if args.cpu_seconds > 0:
@@ -511,7 +526,7 @@ def main():
         else:
             workload = (f"non-headline geometry: batch of {G} synthetic 80-band mels over {n_gpus} GPU(s), n_fft {N}, "
                         f"hop {H}, {T} frames, mel->linear + Griffin-Lim {K} iters + peak normalise")
-        traffic, traffic_note = traffic_for(_lib.LIB_PATH, default_cfg, args.path == 0)
+        traffic, traffic_note, k1 = traffic_for(_lib.LIB_PATH, default_cfg, args.path == 0)
         out = {
             "metric": f"audio-seconds reconstructed/sec (GL {K} iters, n_fft {N})",
             "value": value, "unit": "audio-s/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
@@ -535,6 +550,18 @@ def main():
             "outputs_finite": finite,
             "hipgraph_ms_per_step": graph_ms,
         }
+        if k1 is not None and one_call and "avg_us" in k1:
+            c = k1.get("counters_per_launch", {})
+            out["roofline_k1"] = {
+                "bound": "mfma", "kernel": "k_mel_to_mag<false, true, true> (mel -> linear magnitudes in the loop's packed "
+                                           "layout, inside gl_mel_run; 1 of the step's 63 launches)",
+                "achieved": k1["achieved_TFLOPs"], "peak": VALU_FP32_PEAK_TF, "unit": "TFLOP/s", "frac": k1["frac"],
+                "avg_launch_us": k1["avg_us"], "useful_flops_per_launch": k1["useful_flops_per_launch"],
+                "mfma_flops_issued_per_launch": k1.get("mfma_flops_issued_per_launch"),
+                "mfma_busy_share_of_simd_time": (c["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * c["SQ_BUSY_CU_CYCLES"])
+                                               if c.get("SQ_BUSY_CU_CYCLES") else None),
+                "source": "stored rocprofv3 record of this library (kernel trace + --pmc pass, profiles/r3_traffic.json: "
+                          "k1); fp32-input MFMA peak = the fp32 vector peak on gfx950"}
         if rccl is not None:
             out["rccl"] = rccl
         if args.cpu_seconds > 0:

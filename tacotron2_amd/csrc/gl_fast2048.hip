@@ -547,6 +547,19 @@ __global__ void __launch_bounds__(64 * kRRWaves, 1) k_gl2048_regring(AlignedArgs
         for (int jj = 0; jj < HS; ++jj) accr[OVR + jj] = (v2f){0.0f, 0.0f};
     };
 
+#if defined(GL_EXPERIMENT) && defined(GL_REPS)
+    // timing study (wrong numbers): GL_REPS iterations inside ONE launch with NO hand-over between runs -- the upper
+    // bound of what a persistent several-iterations-per-launch kernel with neighbour flags could gain (it would
+    // pay for its flags and cache maintenance on top).  The host launches iters / GL_REPS kernels.
+#pragma nounroll
+    for (int rep = 0; rep < GL_REPS; ++rep) {
+    if (rep) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { xraw[j] = load_row(128 * j); accr[j] = (v2f){0.0f, 0.0f}; }
+        load_mags(f0, mm, m512);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+    }
+#endif
     // prologue: forward transform of the run's first frame (zB), windowed input of its second (zA)
     v2f zA[16], zB[16];
     {
@@ -620,6 +633,9 @@ __global__ void __launch_bounds__(64 * kRRWaves, 1) k_gl2048_regring(AlignedArgs
 #pragma unroll
         for (int j = 0; j < OVR; ++j) *reinterpret_cast<v2f*>(trow + 128 * j) = accr[j];
     }
+#if defined(GL_EXPERIMENT) && defined(GL_REPS)
+    }
+#endif
 }
 
 // =====================================================================================
@@ -874,6 +890,9 @@ int run_regring(gl_plan* p, const float* mag, const float* x0, float* x_out, int
     const float* src_tail = nullptr;
     const bool post = gl_post_needed(p);
     int rc = 0;
+#if defined(GL_EXPERIMENT) && defined(GL_REPS)
+    iters = (iters + GL_REPS - 1) / GL_REPS;
+#endif
     for (int it = 0; it < iters; ++it) {
         const bool last = (it == iters - 1);
         float* dst = (it & 1) ? p->d_xb : p->d_xa;

@@ -54,7 +54,7 @@ def test_bench_line_numbers_are_consistent(line):
 
 def test_traffic_record_belongs_to_the_library_in_the_tree():
     """bench.py stamps `traffic` only into runs that loaded the library the counters were taken with."""
-    with open(os.path.join(ROOT, "profiles", "r2_traffic.json")) as fh:
+    with open(os.path.join(ROOT, "profiles", "r3_traffic.json")) as fh:
         rec = json.load(fh)
     lib = os.path.join(ROOT, "tacotron2_amd", "libgl_hip.so")
     if not os.path.exists(lib):

@@ -8,7 +8,7 @@ for ctrs in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY
             "SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_RD SQ_IFETCH SQ_INSTS_SMEM SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_LEVEL_WAVES"; do
   i=$((i+1))
   rm -rf /tmp/pmc_$i
-  timeout -s KILL 90 rocprofv3 --pmc $ctrs --output-format csv -d /tmp/pmc_$i -- python3 /root/repo/bench.py --steps 1 --warmup 0 --preroll-ms 0 --cpu-seconds 0 --graph 0 > /tmp/pmc_$i.log 2>&1 || { echo "pass $i failed"; tail -5 /tmp/pmc_$i.log; exit 1; }
+  timeout -s KILL 90 rocprofv3 --pmc $ctrs --output-format csv -d /tmp/pmc_$i -- python3 /root/repo/bench.py --steps 1 --warmup 0 --preroll-ms 0 --cpu-seconds 0 --graph 0 --secondary 0 > /tmp/pmc_$i.log 2>&1 || { echo "pass $i failed"; tail -5 /tmp/pmc_$i.log; exit 1; }
   f=$(ls /tmp/pmc_$i/*/*counter_collection.csv | head -1)
   python3 - "$f" <<'PY' > /root/repo/gpurun_out/pmc_${tag}_$i.txt
 import csv, sys, collections

@@ -9,7 +9,7 @@ for ctrs in "FETCH_SIZE TCC_REQ_sum" \
             "TCP_PENDING_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_LFIFO_STALL_CYCLES_sum TCP_RFIFO_STALL_CYCLES_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_TA_BUSY_sum GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   rm -rf /tmp/pmcm_$i
-  timeout -s KILL 90 rocprofv3 --pmc $ctrs --output-format csv -d /tmp/pmcm_$i -- python3 /root/repo/bench.py --steps 1 --warmup 0 --preroll-ms 0 --cpu-seconds 0 --graph 0 > /tmp/pmcm_$i.log 2>&1 || { echo "pass $i failed"; tail -5 /tmp/pmcm_$i.log; exit 1; }
+  timeout -s KILL 90 rocprofv3 --pmc $ctrs --output-format csv -d /tmp/pmcm_$i -- python3 /root/repo/bench.py --steps 1 --warmup 0 --preroll-ms 0 --cpu-seconds 0 --graph 0 --secondary 0 > /tmp/pmcm_$i.log 2>&1 || { echo "pass $i failed"; tail -5 /tmp/pmcm_$i.log; exit 1; }
   f=$(ls /tmp/pmcm_$i/*/*counter_collection.csv | head -1)
   python3 - "$f" <<'PY' > /root/repo/gpurun_out/pmcmem_${tag}_$i.txt
 import csv, sys, collections

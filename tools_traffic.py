@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r2_traffic.json from the memory-side PMC passes of tools_pmc_mem.sh <tag>:
+"""profiles/r3_traffic.json from the memory-side PMC passes of tools_pmc_mem.sh <tag>:
 
     python tools_traffic.py <tag>
 
@@ -44,6 +44,34 @@ rec = {
     "git_head": subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip(),
     "files": [f"profiles/{tag}_pmc_mem_pass1.txt", f"profiles/{tag}_pmc_mem_pass2.txt"],
 }
-with open(os.path.join(ROOT, "profiles", "r2_traffic.json"), "w") as fh:
+# K1 on the bench path (k_mel_to_mag<false, true, true>, the PACKED instance gl_mel_run launches): MFMA counters of
+# tools_pmc_k1.sh, when that pass has been run for this tag
+k1_path = os.path.join(ROOT, "gpurun_out", f"pmck1_{tag}.txt")
+if os.path.exists(k1_path):
+    k1 = {}
+    for line in open(k1_path):
+        m = re.match(r"(\S.*?) (SQ_\w+|GRBM_\w+) per-dispatch ([0-9.e+]+) dispatches (\d+)", line.strip())
+        if m:
+            k1[m.group(2)] = float(m.group(3))
+            k1["kernel"] = m.group(1)
+    useful = 2.0 * F * 80 * T * B                      # griffin_lim.py:18: (F x 80) . (80 x T) per utterance
+    rec["k1"] = {"counters_per_launch": k1, "useful_flops_per_launch": useful,
+                 "mfma_flops_issued_per_launch": k1.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0) * 512.0,
+                 "file": f"profiles/{tag}_pmc_mel_run.txt",
+                 "note": "SQ_INSTS_VALU_MFMA_MOPS_F32 counts units of 512 flops; SQ_VALU_MFMA_BUSY_CYCLES / "
+                         "(4 x SQ_BUSY_CU_CYCLES): SIMD-cycles with the matrix pipe busy over the SIMD-cycles of the busy CUs (one MFMA 32x32x2 f32 = 64 cycles)"}
+    rec["files"].append(f"profiles/{tag}_pmc_mel_run.txt")
+    ks = os.path.join(ROOT, "gpurun_out", f"prof_{tag}", "kernel_stats.csv")
+    if os.path.exists(ks):
+        import csv
+        for row in csv.DictReader(open(ks)):
+            if "k_mel_to_mag<false, true, true>" in row["Name"]:
+                us = float(row["AverageNs"]) / 1e3
+                rec["k1"].update({"avg_us": us, "dispatches": int(row["Calls"]), "achieved_TFLOPs": useful / us / 1e6,
+                                  "peak_TFLOPs": 157.3, "frac": useful / us / 1e6 / 157.3,
+                                  "kernel_trace": f"profiles/{tag}_kernel_stats.csv"})
+            if "k_gl2048_regring<2>" in row["Name"]:
+                rec["dominant_kernel_avg_us_kernel_trace"] = float(row["AverageNs"]) / 1e3
+with open(os.path.join(ROOT, "profiles", "r3_traffic.json"), "w") as fh:
     json.dump(rec, fh, indent=1)
 print(json.dumps(rec, indent=1))

@@ -1,5 +1,5 @@
 """The driver reads ONE JSON line from bench.py.  The committed line of the round's final library
-(profiles/r2b_bench.json, written by `python bench.py` on an MI355X) must carry every field of that contract, and
+(profiles/r3_bench.json, written by `python bench.py` on an MI355X) must carry every field of that contract, and
 its numbers must be consistent with each other -- the same arithmetic the reviewer applies."""
 import hashlib
 import json
@@ -8,7 +8,7 @@ import os
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LINE = os.path.join(ROOT, "profiles", "r2b_bench.json")
+LINE = os.path.join(ROOT, "profiles", "r3_bench.json")
 
 
 @pytest.fixture(scope="module")
@@ -50,6 +50,30 @@ def test_bench_line_numbers_are_consistent(line):
     # counter traffic: measured, at least the algorithmic bytes, and not wildly above them
     assert r["traffic"] is not None and algo <= r["traffic"] <= 1.5 * algo
     assert line["parity"]["ok"] and line["parity"]["max_err_over_peak"] <= line["parity"]["tolerance"]
+
+
+def test_bench_line_carries_the_other_configurations(line):
+    """Round 3: configs 1, 4, 5 and the 128-utterance shard are measured by the driver's own run (`secondary`), each
+    with consistent throughput / roofline arithmetic and a parity figure against the oracle, and the mel inversion on
+    the bench path has its MFMA roofline (`roofline_k1`)."""
+    sec = line["secondary"]
+    for name, geom in (("config1", (1024, 275)), ("config5", (1024, 275)), ("shard128", (2048, 256)), ("config4", (2048, 256))):
+        c = sec[name]
+        N, H = geom
+        L = c["frames"] * H + N
+        assert c["audio_s_per_s"] == pytest.approx(c["batch"] * L / 22050.0 / (c["ms_per_call"] * 1e-3), rel=1e-6)
+        assert c["algorithmic_bytes_per_launch"] == c["batch"] * (c["frames"] * (N // 2 + 1) * 4 + 2 * L * 4)
+        assert c["frac"] == pytest.approx(c["algorithmic_bytes_per_launch"] / (c["iter_us"] * 1e-6) / 1e9 / 8000.0, rel=1e-6)
+        assert c["iters"] * c["iter_us"] * 1e-3 <= c["ms_per_call"] * 1.02
+    for name in ("config1", "config5"):
+        assert sec[name]["parity"]["max_err_over_peak"] <= 1e-3 and sec[name]["parity"]["sc_delta"] <= 1e-3
+    p4 = sec["config4"]["parity"]
+    assert p4["windows_max_err_over_peak"] <= 1e-3 and p4["windows"] == 25
+    assert p4["over_tol_blocks"] <= 2 * p4["numpy_float32_over_tol_blocks"] + 2 and p4["worst_block"] <= 2 * p4["numpy_float32_worst_block"]
+    k1 = line["roofline_k1"]
+    assert k1["bound"] == "mfma" and k1["unit"] == "TFLOP/s" and k1["peak"] == 157.3
+    assert k1["frac"] == pytest.approx(k1["useful_flops_per_launch"] / (k1["avg_launch_us"] * 1e-6) / 1e12 / 157.3, rel=1e-6)
+    assert k1["useful_flops_per_launch"] <= k1["mfma_flops_issued_per_launch"] <= 1.1 * k1["useful_flops_per_launch"]
 
 
 def test_traffic_record_belongs_to_the_library_in_the_tree():

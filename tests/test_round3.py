@@ -138,7 +138,12 @@ def test_n1_entry_points_at_config5_size(tmp_path, monkeypatch):
 def test_rccl_world_of_one_rank_on_the_real_stack():
     """sharding.reconstruct_sharded(..., gather=True) over the "nccl" backend (RCCL) with device tensors, in a child
     process: init on the device, barrier, all_reduce, the padded all_gather right behind the library's kernels."""
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import socket
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     pr = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "rccl_world1.py")], env=env,
                         capture_output=True, text=True, timeout=300)
     assert pr.returncode == 0, pr.stdout[-2000:] + pr.stderr[-2000:]

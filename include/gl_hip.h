@@ -13,7 +13,7 @@
  *     calls (gl_run, gl_stft, gl_istft, gl_mel_to_mag, ...) only enqueue kernels / async
  *     memsets and copies on `stream` and return: no allocation, no synchronisation, no
  *     blocking copy -- legal inside a stream capture.  Memory is allocated and tables are
- *     uploaded (blocking) only by the configuration calls gl_plan_create, gl_plan_set_path
+ *     uploaded (blocking) only by the configuration calls gl_plan_create[_capacity], gl_plan_set_path
  *     and gl_plan_set_options.
  *   - Every function returns 0 on success or a negative gl_status; the text of the
  *     last failure on the calling thread is returned by gl_last_error().

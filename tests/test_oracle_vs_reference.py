@@ -44,3 +44,32 @@ def test_loop_forms(ref, N, H, T):
     np.random.seed(7)
     y = orc.griffin_lim_loop(mag, N, H, 4)
     assert np.array_equal(y, y_ref)
+
+
+def test_host_helpers_equal_the_reference(ref, tmp_path):
+    """The unused-but-public helpers of audio_utilities.py:14-74,117-151 (API-surface completeness): the
+    drop-in's versions return what the imported reference returns, value for value."""
+    import scipy.io.wavfile
+    from tacotron2_amd import audio_utilities as au
+    for f in (0.0, 125.0, 700.0, 1234.5, 7600.0, 11025.0):
+        assert au.hz_to_mel(f) == ref.hz_to_mel(f)
+        assert au.mel_to_hz(au.hz_to_mel(f)) == ref.mel_to_hz(ref.hz_to_mel(f))
+    for n_bin, n_fft in ((0, 1024), (10, 1024), (511, 1024), (37, 2048)):
+        assert au.fft_bin_to_hz(n_bin, 22050, n_fft) == ref.fft_bin_to_hz(n_bin, 22050, n_fft)
+    for f in (0.0, 999.9, 1000.0, 5512.5, 11025.0, 1e9):
+        assert au.hz_to_fft_bin(f, 22050, 1024) == ref.hz_to_fft_bin(f, 22050, 1024)
+    # get_signal: 16-bit mono and stereo files, and the sample-rate check (audio_utilities.py:117-151)
+    rng = np.random.default_rng(2)
+    mono = (rng.standard_normal(3000) * 8000).astype(np.int16)
+    stereo = (rng.standard_normal((3000, 2)) * 8000).astype(np.int16)
+    for name, data in (("mono.wav", mono), ("stereo.wav", stereo)):
+        path = str(tmp_path / name)
+        scipy.io.wavfile.write(path, 44100, data)
+        assert np.array_equal(au.get_signal(path), ref.get_signal(path))
+    path = str(tmp_path / "sr.wav")
+    scipy.io.wavfile.write(path, 22050, mono)
+    assert np.array_equal(au.get_signal(path, expected_fs=22050), ref.get_signal(path, expected_fs=22050))
+    with pytest.raises(Exception):
+        ref.get_signal(path)
+    with pytest.raises(Exception):
+        au.get_signal(path)
